@@ -1,0 +1,867 @@
+// extern "C" surface of libcugraph_amd_c.so (declarations and reference citations:
+// include/cugraph_amd_c.h).  Host-only glue: argument checks in the order the reference makes
+// them (cpp/src/c_api/graph_sg.cpp:545-593, cpp/src/c_api/pagerank.cpp:268-299), the
+// exception -> error-code boundary (cpp/src/c_api/utils.hpp:23-59), and buffer ownership.
+#include "common.hpp"
+
+#include <cstring>
+#include <memory>
+
+namespace cga {
+// pagerank.hip
+struct Session;
+Session* session_create(Handle const& h, Graph& g, PagerankArgs const& a);
+void session_iterate(Session& s, size_t n);
+void session_timed_iterate(Session& s, size_t n, float* iter_ms, float* kernel_ms);
+void session_status(Session& s, size_t* iters, bool* stopped, double* delta, double* dangling);
+CentralityResult* session_result(Session& s, size_t max_iterations);
+void session_info(Session& s, int64_t info[8]);
+void session_exchange_buffers(Session& s, void** x_full, void** scalars);
+void session_destroy(Session* s);
+bool session_is_f64(Session& s);
+int64_t session_num_global(Session& s);
+void compute_source_sums(hipStream_t stream, Graph const& g, double* sums);
+}  // namespace cga
+
+using namespace cga;
+
+namespace {
+
+template <typename T, typename P>
+T* as(P* p)
+{
+  return reinterpret_cast<T*>(p);
+}
+template <typename T, typename P>
+T const* as(P const* p)
+{
+  return reinterpret_cast<T const*>(p);
+}
+
+cugraph_error_code_t fail(cugraph_error_t** error, cugraph_error_code_t code, std::string const& msg)
+{
+  if (error) *error = reinterpret_cast<cugraph_error_t*>(new Error{msg});
+  return code;
+}
+
+// Runs body(); maps exceptions to the reference's error convention.
+template <typename F>
+cugraph_error_code_t guarded(cugraph_error_t** error, F&& body)
+{
+  if (error) *error = nullptr;
+  try {
+    body();
+  } catch (Failure const& f) {
+    return fail(error, f.code, f.what());
+  } catch (std::bad_alloc const&) {
+    return fail(error, CUGRAPH_ALLOC_ERROR, "host allocation failed");
+  } catch (std::exception const& ex) {
+    return fail(error, CUGRAPH_UNKNOWN_ERROR, ex.what());
+  }
+  return CUGRAPH_SUCCESS;
+}
+
+ArrayView* new_view(void* p, size_t n, cugraph_data_type_id_t t)
+{
+  return new ArrayView{p, n, n * dtype_size(t), t};
+}
+
+bool is_float_type(cugraph_data_type_id_t t) { return t == FLOAT32 || t == FLOAT64; }
+bool is_int_type(cugraph_data_type_id_t t) { return t == INT32 || t == INT64; }
+
+Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, ArrayView const* vertices,
+                  ArrayView const* src, ArrayView const* dst, ArrayView const* weights,
+                  bool store_transposed, bool renumber, bool drop_self_loops, bool drop_multi_edges,
+                  int64_t vertex_first, int64_t vertex_last, int64_t num_global /* <0: single GPU */)
+{
+  CGA_EXPECTS(src && dst, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src and dst are required.");
+  CGA_EXPECTS(src->size == dst->size, CUGRAPH_INVALID_INPUT,
+              "Invalid input arguments: src size != dst size.");
+  CGA_EXPECTS(!vertices || src->type == vertices->type, CUGRAPH_INVALID_INPUT,
+              "Invalid input arguments: src type != vertices type.");
+  CGA_EXPECTS(src->type == dst->type, CUGRAPH_INVALID_INPUT,
+              "Invalid input arguments: src type != dst type.");
+  CGA_EXPECTS(!weights || weights->size == src->size, CUGRAPH_INVALID_INPUT,
+              "Invalid input arguments: src size != weights size.");
+  CGA_EXPECTS(is_int_type(src->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+              "vertex ids must be INT32 or INT64");
+  CGA_EXPECTS(!weights || is_float_type(weights->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+              "edge weights must be FLOAT32 or FLOAT64");
+  CGA_EXPECTS(!renumber, CUGRAPH_NOT_IMPLEMENTED,
+              "renumber=TRUE is not implemented yet: pass contiguous ids 0..V-1 with renumber=FALSE");
+  CGA_EXPECTS(!drop_self_loops && !drop_multi_edges, CUGRAPH_NOT_IMPLEMENTED,
+              "drop_self_loops / drop_multi_edges are not implemented");
+
+  hipStream_t stream = h.stream;
+  int64_t ne         = static_cast<int64_t>(src->size);
+  DevBuf s32(static_cast<size_t>(ne > 0 ? ne : 1) * 4), d32(static_cast<size_t>(ne > 0 ? ne : 1) * 4);
+  int64_t smin = 0, dmin = 0;
+  int64_t smax = narrow_ids(stream, src->data, src->type, src->size, s32.as<int32_t>(), &smin);
+  int64_t dmax = narrow_ids(stream, dst->data, dst->type, dst->size, d32.as<int32_t>(), &dmin);
+
+  auto g              = std::make_unique<Graph>();
+  g->vertex_type      = src->type;
+  // edge_t := INT64 iff n_edges >= INT32_MAX (graph_sg.cpp:568-572)
+  g->edge_type        = static_cast<size_t>(ne) < 0x7fffffffULL ? src->type : INT64;
+  g->weight_type      = weights ? weights->type : FLOAT32;  // graph_sg.cpp:574-578
+  g->store_transposed = store_transposed;
+  g->is_symmetric     = props && props->is_symmetric;
+  g->is_multigraph    = props && props->is_multigraph;
+  g->num_edges        = ne;
+
+  int64_t n_major, n_minor, major_shift = 0;
+  if (num_global >= 0) {  // local part of a 1D destination partition
+    CGA_EXPECTS(store_transposed, CUGRAPH_INVALID_INPUT, "a partitioned graph is always stored transposed");
+    CGA_EXPECTS(0 <= vertex_first && vertex_first <= vertex_last && vertex_last <= num_global,
+                CUGRAPH_INVALID_INPUT, "invalid local vertex range");
+    CGA_EXPECTS(ne == 0 || (dmin >= vertex_first && dmax < vertex_last), CUGRAPH_INVALID_INPUT,
+                "destination ids outside this rank's vertex range");
+    CGA_EXPECTS(ne == 0 || (smin >= 0 && smax < num_global), CUGRAPH_INVALID_INPUT,
+                "source ids outside [0, num_global_vertices)");
+    g->num_vertices        = vertex_last - vertex_first;
+    g->num_global_vertices = num_global;
+    g->vertex_first        = vertex_first;
+    n_major                = g->num_vertices;
+    n_minor                = num_global;
+    major_shift            = vertex_first;
+  } else {
+    // create_graph_from_edgelist_impl.cuh:939-949
+    int64_t nv = vertices ? static_cast<int64_t>(vertices->size)
+                          : 1 + std::max<int64_t>(smax, dmax);
+    if (ne == 0 && !vertices) nv = 0;
+    CGA_EXPECTS(ne == 0 || (smin >= 0 && dmin >= 0), CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: negative vertex ids need renumber=TRUE.");
+    CGA_EXPECTS(ne == 0 || (smax < nv && dmax < nv), CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: vertex ids must lie in [0, number of vertices) when "
+                "renumber=FALSE.");
+    g->num_vertices = g->num_global_vertices = nv;
+    n_major = n_minor = nv;
+  }
+  CGA_EXPECTS(n_minor < 0x7fffffffLL, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+              "2^31 or more vertices are not supported");
+
+  int32_t* majors = store_transposed ? d32.as<int32_t>() : s32.as<int32_t>();
+  int32_t* minors = store_transposed ? s32.as<int32_t>() : d32.as<int32_t>();
+  DevBuf shifted;
+  if (major_shift != 0 && ne > 0) {
+    // local major ids = global id - vertex_first (partitioned build only)
+    shifted.alloc(static_cast<size_t>(ne) * 4);
+    shift_ids(stream, majors, shifted.as<int32_t>(), ne, major_shift);
+    majors = shifted.as<int32_t>();
+  }
+  CompressedOut out = compress_coo(stream, n_major, n_minor, ne, majors, minors,
+                                   weights ? weights->data : nullptr,
+                                   weights ? dtype_size(weights->type) : 0);
+  g->off64   = out.off64;
+  g->offsets = out.offsets.detach();
+  g->indices = static_cast<int32_t*>(out.indices.detach());
+  g->weights = out.weights.p ? out.weights.detach() : nullptr;
+  return g.release();
+}
+
+cugraph_error_code_t check_pair_types(Graph const* g, ArrayView const* v, ArrayView const* x,
+                                      char const* vmsg, char const* xmsg, cugraph_error_t** error)
+{
+  if (v != nullptr) {
+    if (g->vertex_type != v->type) return fail(error, CUGRAPH_INVALID_INPUT, vmsg);
+    if (x == nullptr || g->weight_type != x->type) return fail(error, CUGRAPH_INVALID_INPUT, xmsg);
+  }
+  return CUGRAPH_SUCCESS;
+}
+
+cugraph_error_code_t pagerank_entry(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                    const cugraph_type_erased_device_array_view_t* pre_v,
+                                    const cugraph_type_erased_device_array_view_t* pre_s,
+                                    const cugraph_type_erased_device_array_view_t* guess_v,
+                                    const cugraph_type_erased_device_array_view_t* guess_x,
+                                    const cugraph_type_erased_device_array_view_t* pers_v,
+                                    const cugraph_type_erased_device_array_view_t* pers_x,
+                                    double alpha, double epsilon, size_t max_iterations,
+                                    bool_t do_expensive_check, bool must_converge,
+                                    cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  if (error) *error = nullptr;
+  if (result) *result = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph || !result) return fail(error, CUGRAPH_INVALID_INPUT, "graph / result pointer is NULL");
+  auto* g = as<Graph>(graph);
+  cugraph_error_code_t rc;
+  rc = check_pair_types(g, as<ArrayView>(pre_v), as<ArrayView>(pre_s),
+                        "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
+                        "vertex type of graph and precomputed_vertex_out_weight_sums must match", error);
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  rc = check_pair_types(g, as<ArrayView>(guess_v), as<ArrayView>(guess_x),
+                        "vertex type of graph and initial_guess_vertices must match",
+                        "vertex type of graph and initial_guess_values must match", error);
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  rc = check_pair_types(g, as<ArrayView>(pers_v), as<ArrayView>(pers_x),
+                        "vertex type of graph and personalization_vector must match",
+                        "vertex type of graph and personalization_vector must match", error);
+  if (rc != CUGRAPH_SUCCESS) return rc;
+
+  PagerankArgs a;
+  a.pre_vertices       = as<ArrayView>(pre_v);
+  a.pre_sums           = as<ArrayView>(pre_s);
+  a.guess_vertices     = as<ArrayView>(guess_v);
+  a.guess_values       = as<ArrayView>(guess_x);
+  a.pers_vertices      = as<ArrayView>(pers_v);
+  a.pers_values        = as<ArrayView>(pers_x);
+  a.alpha              = alpha;
+  a.epsilon            = epsilon;
+  a.max_iterations     = max_iterations;
+  a.do_expensive_check = do_expensive_check != FALSE;
+  CentralityResult* res = nullptr;
+  rc = guarded(error, [&] { res = run_pagerank(*as<Handle>(handle), *g, a); });
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  *result = reinterpret_cast<cugraph_centrality_result_t*>(res);
+  // pagerank.cpp:315-318: the strict variants report non-convergence but leave *result populated
+  if (must_converge && !res->converged)
+    return fail(error, CUGRAPH_UNKNOWN_ERROR, "PageRank failed to converge.");
+  return CUGRAPH_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ errors
+const char* cugraph_error_message(const cugraph_error_t* error)
+{
+  return error ? as<Error>(error)->message.c_str() : nullptr;
+}
+void cugraph_error_free(cugraph_error_t* error) { delete as<Error>(error); }
+
+// ------------------------------------------------------------------ handle
+cugraph_resource_handle_t* cugraph_amd_create_resource_handle(void* hip_stream, int rank, int comm_size)
+{
+  try {
+    auto h       = std::make_unique<Handle>();
+    h->stream    = static_cast<hipStream_t>(hip_stream);
+    h->rank      = rank;
+    h->comm_size = comm_size < 1 ? 1 : comm_size;
+    if (hipGetDevice(&h->device) != hipSuccess) return nullptr;
+    return reinterpret_cast<cugraph_resource_handle_t*>(h.release());
+  } catch (...) {
+    return nullptr;
+  }
+}
+cugraph_resource_handle_t* cugraph_create_resource_handle(void* raft_handle)
+{
+  if (raft_handle != nullptr) return nullptr;  // there is no raft here; see the header
+  return cugraph_amd_create_resource_handle(nullptr, 0, 1);
+}
+int cugraph_resource_handle_get_comm_size(const cugraph_resource_handle_t* handle)
+{
+  return handle ? as<Handle>(handle)->comm_size : 1;
+}
+int cugraph_resource_handle_get_rank(const cugraph_resource_handle_t* handle)
+{
+  return handle ? as<Handle>(handle)->rank : 0;
+}
+void cugraph_free_resource_handle(cugraph_resource_handle_t* handle) { delete as<Handle>(handle); }
+
+// ------------------------------------------------------------------ device arrays
+cugraph_error_code_t cugraph_type_erased_device_array_create(const cugraph_resource_handle_t* handle,
+                                                             size_t n_elems,
+                                                             cugraph_data_type_id_t dtype,
+                                                             cugraph_type_erased_device_array_t** array,
+                                                             cugraph_error_t** error)
+{
+  if (array) *array = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    CGA_EXPECTS(array && dtype_size(dtype) > 0, CUGRAPH_INVALID_INPUT, "bad array arguments");
+    auto a    = std::make_unique<Array>();
+    a->size   = n_elems;
+    a->type   = dtype;
+    a->nbytes = n_elems * dtype_size(dtype);
+    if (a->nbytes) CGA_HIP(hipMalloc(&a->data, a->nbytes));
+    *array = reinterpret_cast<cugraph_type_erased_device_array_t*>(a.release());
+  });
+}
+
+cugraph_error_code_t cugraph_type_erased_device_array_create_from_view(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* view,
+  cugraph_type_erased_device_array_t** array, cugraph_error_t** error)
+{
+  if (array) *array = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    CGA_EXPECTS(array && view, CUGRAPH_INVALID_INPUT, "bad array arguments");
+    auto const* v = as<ArrayView>(view);
+    auto a        = std::make_unique<Array>();
+    a->size = v->size; a->type = v->type; a->nbytes = v->nbytes;
+    hipStream_t st = as<Handle>(handle)->stream;
+    if (a->nbytes) {
+      CGA_HIP(hipMalloc(&a->data, a->nbytes));
+      CGA_HIP(hipMemcpyAsync(a->data, v->data, a->nbytes, hipMemcpyDeviceToDevice, st));
+      CGA_HIP(hipStreamSynchronize(st));
+    }
+    *array = reinterpret_cast<cugraph_type_erased_device_array_t*>(a.release());
+  });
+}
+
+void cugraph_type_erased_device_array_free(cugraph_type_erased_device_array_t* p) { delete as<Array>(p); }
+
+cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view(
+  cugraph_type_erased_device_array_t* array)
+{
+  if (!array) return nullptr;
+  auto* a = as<Array>(array);
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(a->data, a->size, a->type));
+}
+
+cugraph_error_code_t cugraph_type_erased_device_array_view_as_type(
+  cugraph_type_erased_device_array_t* array, cugraph_data_type_id_t dtype,
+  cugraph_type_erased_device_array_view_t** result_view, cugraph_error_t** error)
+{
+  if (result_view) *result_view = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(array && result_view, CUGRAPH_INVALID_INPUT, "bad array arguments");
+    auto* a = as<Array>(array);
+    CGA_EXPECTS(dtype_size(dtype) == dtype_size(a->type) && dtype_size(dtype) > 0, CUGRAPH_INVALID_INPUT,
+                "Could not treat type erased device array as a different type: sizes differ");
+    *result_view = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(a->data, a->size, dtype));
+  });
+}
+
+cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view_create(
+  void* pointer, size_t n_elems, cugraph_data_type_id_t dtype)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(pointer, n_elems, dtype));
+}
+void cugraph_type_erased_device_array_view_free(cugraph_type_erased_device_array_view_t* p) { delete as<ArrayView>(p); }
+size_t cugraph_type_erased_device_array_view_size(const cugraph_type_erased_device_array_view_t* p) { return as<ArrayView>(p)->size; }
+cugraph_data_type_id_t cugraph_type_erased_device_array_view_type(const cugraph_type_erased_device_array_view_t* p) { return as<ArrayView>(p)->type; }
+const void* cugraph_type_erased_device_array_view_pointer(const cugraph_type_erased_device_array_view_t* p) { return as<ArrayView>(p)->data; }
+
+// ------------------------------------------------------------------ host arrays
+cugraph_error_code_t cugraph_type_erased_host_array_create(const cugraph_resource_handle_t* handle,
+                                                           size_t n_elems, cugraph_data_type_id_t dtype,
+                                                           cugraph_type_erased_host_array_t** array,
+                                                           cugraph_error_t** error)
+{
+  if (array) *array = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    CGA_EXPECTS(array && dtype_size(dtype) > 0, CUGRAPH_INVALID_INPUT, "bad array arguments");
+    auto a    = std::make_unique<HostArray>();
+    a->size   = n_elems;
+    a->type   = dtype;
+    a->nbytes = n_elems * dtype_size(dtype);
+    a->data   = ::operator new(a->nbytes ? a->nbytes : 1);
+    *array    = reinterpret_cast<cugraph_type_erased_host_array_t*>(a.release());
+  });
+}
+void cugraph_type_erased_host_array_free(cugraph_type_erased_host_array_t* p) { delete as<HostArray>(p); }
+cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view(cugraph_type_erased_host_array_t* array)
+{
+  if (!array) return nullptr;
+  auto* a = as<HostArray>(array);
+  return reinterpret_cast<cugraph_type_erased_host_array_view_t*>(
+    new HostArrayView{a->data, a->size, a->nbytes, a->type});
+}
+cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view_create(void* pointer, size_t n_elems, cugraph_data_type_id_t dtype)
+{
+  return reinterpret_cast<cugraph_type_erased_host_array_view_t*>(
+    new HostArrayView{pointer, n_elems, n_elems * dtype_size(dtype), dtype});
+}
+void cugraph_type_erased_host_array_view_free(cugraph_type_erased_host_array_view_t* p) { delete as<HostArrayView>(p); }
+size_t cugraph_type_erased_host_array_size(const cugraph_type_erased_host_array_view_t* p) { return as<HostArrayView>(p)->size; }
+cugraph_data_type_id_t cugraph_type_erased_host_array_type(const cugraph_type_erased_host_array_view_t* p) { return as<HostArrayView>(p)->type; }
+void* cugraph_type_erased_host_array_pointer(const cugraph_type_erased_host_array_view_t* p) { return as<HostArrayView>(p)->data; }
+
+cugraph_error_code_t cugraph_type_erased_host_array_view_copy(const cugraph_resource_handle_t*,
+                                                              cugraph_type_erased_host_array_view_t* dst,
+                                                              const cugraph_type_erased_host_array_view_t* src,
+                                                              cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    auto* d = as<HostArrayView>(dst);
+    auto const* s = as<HostArrayView>(src);
+    CGA_EXPECTS(d && s, CUGRAPH_INVALID_INPUT, "bad array arguments");
+    CGA_EXPECTS(d->nbytes == s->nbytes, CUGRAPH_INVALID_INPUT, "Can only copy arrays of the same size");
+    CGA_EXPECTS(d->type == s->type, CUGRAPH_INVALID_INPUT, "Can only copy arrays of the same type");
+    std::memcpy(d->data, s->data, s->nbytes);
+  });
+}
+
+// ------------------------------------------------------------------ copies
+cugraph_error_code_t cugraph_type_erased_device_array_view_copy_from_host(
+  const cugraph_resource_handle_t* handle, cugraph_type_erased_device_array_view_t* dst,
+  const byte_t* h_src, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto* d = as<ArrayView>(dst);
+    CGA_EXPECTS(d && (h_src || d->nbytes == 0), CUGRAPH_INVALID_INPUT, "bad array arguments");
+    hipStream_t st = as<Handle>(handle)->stream;
+    if (d->nbytes) CGA_HIP(hipMemcpyAsync(d->data, h_src, d->nbytes, hipMemcpyHostToDevice, st));
+    CGA_HIP(hipStreamSynchronize(st));
+  });
+}
+
+cugraph_error_code_t cugraph_type_erased_device_array_view_copy_to_host(
+  const cugraph_resource_handle_t* handle, byte_t* h_dst,
+  const cugraph_type_erased_device_array_view_t* src, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto const* s = as<ArrayView>(src);
+    CGA_EXPECTS(s && (h_dst || s->nbytes == 0), CUGRAPH_INVALID_INPUT, "bad array arguments");
+    hipStream_t st = as<Handle>(handle)->stream;
+    if (s->nbytes) CGA_HIP(hipMemcpyAsync(h_dst, s->data, s->nbytes, hipMemcpyDeviceToHost, st));
+    CGA_HIP(hipStreamSynchronize(st));
+  });
+}
+
+cugraph_error_code_t cugraph_type_erased_device_array_view_copy(
+  const cugraph_resource_handle_t* handle, cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* src, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto* d = as<ArrayView>(dst);
+    auto const* s = as<ArrayView>(src);
+    CGA_EXPECTS(d && s, CUGRAPH_INVALID_INPUT, "bad array arguments");
+    // cpp/src/c_api/array.cpp: "Can only copy arrays of the same size / type"
+    CGA_EXPECTS(d->nbytes == s->nbytes, CUGRAPH_INVALID_INPUT, "Can only copy arrays of the same size");
+    CGA_EXPECTS(d->type == s->type, CUGRAPH_INVALID_INPUT, "Can only copy arrays of the same type");
+    hipStream_t st = as<Handle>(handle)->stream;
+    if (s->nbytes) CGA_HIP(hipMemcpyAsync(d->data, s->data, s->nbytes, hipMemcpyDeviceToDevice, st));
+    CGA_HIP(hipStreamSynchronize(st));
+  });
+}
+
+// ------------------------------------------------------------------ graph
+cugraph_error_code_t cugraph_graph_create_sg(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* vertices,
+  const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t do_expensive_check,
+  cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  (void)do_expensive_check;
+  if (graph) *graph = nullptr;
+  if (error) *error = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph) return fail(error, CUGRAPH_INVALID_INPUT, "graph pointer is NULL");
+  return guarded(error, [&] {
+    auto const* s = as<ArrayView>(src);
+    CGA_EXPECTS(s != nullptr, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src is NULL.");
+    auto const* ei = as<ArrayView>(edge_ids);
+    auto const* et = as<ArrayView>(edge_type_ids);
+    // graph_sg.cpp:580-593 (edge ids / types are validated, then not used by this path)
+    cugraph_data_type_id_t edge_type = s->size < 0x7fffffffULL ? s->type : INT64;
+    CGA_EXPECTS(!ei || ei->type == edge_type, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: Edge id type must match edge type");
+    CGA_EXPECTS(!ei || ei->size == s->size, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != edge id prop size");
+    CGA_EXPECTS(!et || et->size == s->size, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != edge type prop size");
+    Graph* g = make_graph(*as<Handle>(handle), properties, as<ArrayView>(vertices), s,
+                          as<ArrayView>(dst), as<ArrayView>(weights), store_transposed != FALSE,
+                          renumber != FALSE, drop_self_loops != FALSE, drop_multi_edges != FALSE, 0, 0, -1);
+    *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_sg_graph_create(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  return cugraph_graph_create_sg(handle, properties, nullptr, src, dst, weights, edge_ids,
+                                 edge_type_ids, store_transposed, renumber, FALSE, FALSE,
+                                 do_expensive_check, graph, error);
+}
+
+cugraph_error_code_t cugraph_graph_create_sg_from_csr(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* offsets,
+  const cugraph_type_erased_device_array_view_t* indices,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  (void)do_expensive_check;
+  if (graph) *graph = nullptr;
+  if (error) *error = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph) return fail(error, CUGRAPH_INVALID_INPUT, "graph pointer is NULL");
+  return guarded(error, [&] {
+    auto const* off = as<ArrayView>(offsets);
+    auto const* idx = as<ArrayView>(indices);
+    auto const* w   = as<ArrayView>(weights);
+    CGA_EXPECTS(off && idx && off->size >= 1, CUGRAPH_INVALID_INPUT, "Invalid input arguments: offsets / indices.");
+    CGA_EXPECTS(!w || w->size == idx->size, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != weights size.");
+    CGA_EXPECTS((edge_ids == nullptr) == (edge_type_ids == nullptr), CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: either none or both of edge ids and edge types must be provided.");
+    CGA_EXPECTS(is_int_type(off->type) && is_int_type(idx->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                "offsets / indices must be INT32 or INT64");
+    // graph_sg.cpp:262-430: the CSR is expanded to an edge list (sources from the offsets) and
+    // then goes through the same build as a COO
+    Handle const& h    = *as<Handle>(handle);
+    int64_t nv         = static_cast<int64_t>(off->size) - 1;
+    int64_t ne         = static_cast<int64_t>(idx->size);
+    DevBuf srcs(static_cast<size_t>(ne > 0 ? ne : 1) * 4);
+    expand_offsets(h.stream, off->data, off->type == INT64, nv, ne, srcs.as<int32_t>());
+    DevBuf verts(static_cast<size_t>(nv > 0 ? nv : 1) * dtype_size(idx->type));
+    fill_sequence(h.stream, verts.p, idx->type, static_cast<size_t>(nv), 0);
+    DevBuf srcs_typed;
+    ArrayView sv{srcs.p, static_cast<size_t>(ne), static_cast<size_t>(ne) * 4, INT32};
+    if (idx->type == INT64) {
+      srcs_typed.alloc(static_cast<size_t>(ne > 0 ? ne : 1) * 8);
+      widen_ids(h.stream, srcs.as<int32_t>(), srcs_typed.as<int64_t>(), ne);
+      sv = ArrayView{srcs_typed.p, static_cast<size_t>(ne), static_cast<size_t>(ne) * 8, INT64};
+    }
+    ArrayView vv{verts.p, static_cast<size_t>(nv), static_cast<size_t>(nv) * dtype_size(idx->type), idx->type};
+    Graph* g = make_graph(h, properties, &vv, &sv, idx, w, store_transposed != FALSE, renumber != FALSE,
+                          false, false, 0, 0, -1);
+    *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_sg_graph_create_from_csr(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* offsets,
+  const cugraph_type_erased_device_array_view_t* indices,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  return cugraph_graph_create_sg_from_csr(handle, properties, offsets, indices, weights, edge_ids,
+                                          edge_type_ids, store_transposed, renumber,
+                                          do_expensive_check, graph, error);
+}
+
+void cugraph_graph_free(cugraph_graph_t* graph) { delete as<Graph>(graph); }
+void cugraph_sg_graph_free(cugraph_graph_t* graph) { cugraph_graph_free(graph); }
+
+cugraph_error_code_t cugraph_amd_graph_create_local(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights, int64_t vertex_first,
+  int64_t vertex_last, int64_t num_global_vertices, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  if (graph) *graph = nullptr;
+  if (error) *error = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph) return fail(error, CUGRAPH_INVALID_INPUT, "graph pointer is NULL");
+  return guarded(error, [&] {
+    CGA_EXPECTS(num_global_vertices >= 0, CUGRAPH_INVALID_INPUT, "num_global_vertices must be >= 0");
+    Graph* g = make_graph(*as<Handle>(handle), properties, nullptr, as<ArrayView>(src),
+                          as<ArrayView>(dst), as<ArrayView>(weights), true, false, false, false,
+                          vertex_first, vertex_last, num_global_vertices);
+    *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_graph_info(const cugraph_graph_t* graph, int64_t info[8],
+                                            cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(graph && info, CUGRAPH_INVALID_INPUT, "graph / info is NULL");
+    auto const* g = as<Graph>(graph);
+    info[0] = g->num_vertices; info[1] = g->num_edges; info[2] = g->num_global_vertices;
+    info[3] = g->vertex_first; info[4] = g->store_transposed; info[5] = g->off64;
+    info[6] = g->weights != nullptr; info[7] = g->renumbered;
+  });
+}
+
+cugraph_error_code_t cugraph_amd_graph_get_compressed(
+  cugraph_graph_t* graph, cugraph_type_erased_device_array_view_t** offsets,
+  cugraph_type_erased_device_array_view_t** indices,
+  cugraph_type_erased_device_array_view_t** weights,
+  cugraph_type_erased_device_array_view_t** number_map, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(graph && offsets && indices && weights && number_map, CUGRAPH_INVALID_INPUT, "NULL argument");
+    auto* g  = as<Graph>(graph);
+    *offsets = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+      new_view(g->offsets, static_cast<size_t>(g->num_vertices + 1), g->off64 ? INT64 : INT32));
+    *indices = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+      new_view(g->indices, static_cast<size_t>(g->num_edges), INT32));
+    *weights = g->weights ? reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(
+                              g->weights, static_cast<size_t>(g->num_edges), g->weight_type))
+                          : nullptr;
+    *number_map = g->number_map ? reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(
+                                    g->number_map, static_cast<size_t>(g->num_vertices), g->vertex_type))
+                                : nullptr;
+  });
+}
+
+cugraph_error_code_t cugraph_amd_graph_source_weight_sums(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  cugraph_type_erased_device_array_view_t* sums, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto* g = as<Graph>(graph);
+    auto* s = as<ArrayView>(sums);
+    CGA_EXPECTS(g && s, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(g->store_transposed, CUGRAPH_INVALID_INPUT, "graph must be stored transposed");
+    CGA_EXPECTS(s->type == FLOAT64 && static_cast<int64_t>(s->size) == g->num_global_vertices,
+                CUGRAPH_INVALID_INPUT, "sums must be FLOAT64 with num_global_vertices elements");
+    hipStream_t st = as<Handle>(handle)->stream;
+    compute_source_sums(st, *g, static_cast<double*>(s->data));
+    CGA_HIP(hipStreamSynchronize(st));
+  });
+}
+
+// ------------------------------------------------------------------ R-MAT
+cugraph_error_code_t cugraph_amd_generate_rmat_edgelist(
+  const cugraph_resource_handle_t* handle, size_t scale, uint64_t first_edge, uint64_t seed,
+  double a, double b, double c, bool_t scramble_vertex_ids,
+  cugraph_type_erased_device_array_view_t* src, cugraph_type_erased_device_array_view_t* dst,
+  cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto* s = as<ArrayView>(src);
+    auto* d = as<ArrayView>(dst);
+    CGA_EXPECTS(s && d && s->type == INT32 && d->type == INT32 && s->size == d->size,
+                CUGRAPH_INVALID_INPUT, "src/dst must be INT32 views of equal size");
+    // generate_rmat_edgelist.cu:48-52
+    CGA_EXPECTS(scale >= 1 && scale <= 30, CUGRAPH_INVALID_INPUT,
+                "Invalid input argument: scale too large for vertex_t.");
+    CGA_EXPECTS(a >= 0.0 && b >= 0.0 && c >= 0.0 && a + b + c <= 1.0, CUGRAPH_INVALID_INPUT,
+                "Invalid input argument: a, b, c should be non-negative and a + b + c should not "
+                "be larger than 1.0.");
+    double ab = a + b;
+    auto thr  = [](double p) { return static_cast<uint32_t>(std::floor(p * 16777216.0)); };
+    uint32_t t_ab = thr(ab), t_a = thr(ab > 0.0 ? a / ab : 0.0),
+             t_c = thr((1.0 - ab) > 0.0 ? c / (1.0 - ab) : 0.0);
+    hipStream_t st = as<Handle>(handle)->stream;
+    rmat_generate(st, static_cast<int>(scale), first_edge, s->size, seed, t_ab, t_a, t_c,
+                  scramble_vertex_ids != FALSE, static_cast<int32_t*>(s->data),
+                  static_cast<int32_t*>(d->data));
+    CGA_HIP(hipStreamSynchronize(st));
+  });
+}
+
+cugraph_error_code_t cugraph_amd_generate_rmat_weights(
+  const cugraph_resource_handle_t* handle, uint64_t first_edge, uint64_t seed,
+  cugraph_type_erased_device_array_view_t* weights, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto* w = as<ArrayView>(weights);
+    CGA_EXPECTS(w && is_float_type(w->type), CUGRAPH_INVALID_INPUT, "weights must be FLOAT32 or FLOAT64");
+    hipStream_t st = as<Handle>(handle)->stream;
+    rmat_weights(st, first_edge, w->size, seed, w->data, w->type == FLOAT64);
+    CGA_HIP(hipStreamSynchronize(st));
+  });
+}
+
+// ------------------------------------------------------------------ centrality result
+cugraph_type_erased_device_array_view_t* cugraph_centrality_result_get_vertices(cugraph_centrality_result_t* result)
+{
+  auto* r = as<CentralityResult>(result);
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+    new_view(r->vertex_ids->data, r->vertex_ids->size, r->vertex_ids->type));
+}
+cugraph_type_erased_device_array_view_t* cugraph_centrality_result_get_values(cugraph_centrality_result_t* result)
+{
+  auto* r = as<CentralityResult>(result);
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+    new_view(r->values->data, r->values->size, r->values->type));
+}
+size_t cugraph_centrality_result_get_num_iterations(cugraph_centrality_result_t* result) { return as<CentralityResult>(result)->num_iterations; }
+bool_t cugraph_centrality_result_converged(cugraph_centrality_result_t* result) { return as<CentralityResult>(result)->converged ? TRUE : FALSE; }
+void cugraph_centrality_result_free(cugraph_centrality_result_t* result) { delete as<CentralityResult>(result); }
+
+// ------------------------------------------------------------------ PageRank
+cugraph_error_code_t cugraph_pagerank(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  return pagerank_entry(handle, graph, precomputed_vertex_out_weight_vertices,
+                        precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                        initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations,
+                        do_expensive_check, true, result, error);
+}
+
+cugraph_error_code_t cugraph_pagerank_allow_nonconvergence(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  return pagerank_entry(handle, graph, precomputed_vertex_out_weight_vertices,
+                        precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                        initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations,
+                        do_expensive_check, false, result, error);
+}
+
+cugraph_error_code_t cugraph_personalized_pagerank(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values,
+  const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  return pagerank_entry(handle, graph, precomputed_vertex_out_weight_vertices,
+                        precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                        initial_guess_values, personalization_vertices, personalization_values,
+                        alpha, epsilon, max_iterations, do_expensive_check, true, result, error);
+}
+
+cugraph_error_code_t cugraph_personalized_pagerank_allow_nonconvergence(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values,
+  const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  return pagerank_entry(handle, graph, precomputed_vertex_out_weight_vertices,
+                        precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                        initial_guess_values, personalization_vertices, personalization_values,
+                        alpha, epsilon, max_iterations, do_expensive_check, false, result, error);
+}
+
+// ------------------------------------------------------------------ session
+cugraph_error_code_t cugraph_amd_pagerank_session_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* pre_v,
+  const cugraph_type_erased_device_array_view_t* pre_s,
+  const cugraph_type_erased_device_array_view_t* guess_v,
+  const cugraph_type_erased_device_array_view_t* guess_x,
+  const cugraph_type_erased_device_array_view_t* pers_v,
+  const cugraph_type_erased_device_array_view_t* pers_x, double alpha, double epsilon,
+  bool_t do_expensive_check, cugraph_amd_pagerank_session_t** session, cugraph_error_t** error)
+{
+  if (session) *session = nullptr;
+  if (error) *error = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph || !session) return fail(error, CUGRAPH_INVALID_INPUT, "graph / session pointer is NULL");
+  auto* g = as<Graph>(graph);
+  cugraph_error_code_t rc;
+  rc = check_pair_types(g, as<ArrayView>(pre_v), as<ArrayView>(pre_s),
+                        "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
+                        "vertex type of graph and precomputed_vertex_out_weight_sums must match", error);
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  rc = check_pair_types(g, as<ArrayView>(guess_v), as<ArrayView>(guess_x),
+                        "vertex type of graph and initial_guess_vertices must match",
+                        "vertex type of graph and initial_guess_values must match", error);
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  rc = check_pair_types(g, as<ArrayView>(pers_v), as<ArrayView>(pers_x),
+                        "vertex type of graph and personalization_vector must match",
+                        "vertex type of graph and personalization_vector must match", error);
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  return guarded(error, [&] {
+    PagerankArgs a;
+    a.pre_vertices = as<ArrayView>(pre_v);     a.pre_sums     = as<ArrayView>(pre_s);
+    a.guess_vertices = as<ArrayView>(guess_v); a.guess_values = as<ArrayView>(guess_x);
+    a.pers_vertices = as<ArrayView>(pers_v);   a.pers_values  = as<ArrayView>(pers_x);
+    a.alpha = alpha; a.epsilon = epsilon; a.do_expensive_check = do_expensive_check != FALSE;
+    *session = reinterpret_cast<cugraph_amd_pagerank_session_t*>(
+      session_create(*as<Handle>(handle), *g, a));
+  });
+}
+
+cugraph_error_code_t cugraph_amd_pagerank_session_iterate(cugraph_amd_pagerank_session_t* session,
+                                                          size_t n, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(session, CUGRAPH_INVALID_INPUT, "session is NULL");
+    session_iterate(*as<Session>(session), n);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_pagerank_session_timed_iterate(
+  cugraph_amd_pagerank_session_t* session, size_t n, float* iteration_ms, float* spmv_kernel_ms,
+  cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(session, CUGRAPH_INVALID_INPUT, "session is NULL");
+    session_timed_iterate(*as<Session>(session), n, iteration_ms, spmv_kernel_ms);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_pagerank_session_exchange_buffers(
+  cugraph_amd_pagerank_session_t* session, cugraph_type_erased_device_array_view_t** x_full,
+  cugraph_type_erased_device_array_view_t** scalars, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(session && x_full && scalars, CUGRAPH_INVALID_INPUT, "NULL argument");
+    auto& s = *as<Session>(session);
+    void *x = nullptr, *sc = nullptr;
+    session_exchange_buffers(s, &x, &sc);
+    *x_full  = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+      new_view(x, static_cast<size_t>(session_num_global(s)), session_is_f64(s) ? FLOAT64 : FLOAT32));
+    *scalars = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(sc, 2, FLOAT64));
+  });
+}
+
+cugraph_error_code_t cugraph_amd_pagerank_session_status(cugraph_amd_pagerank_session_t* session,
+                                                         size_t* num_iterations, bool_t* stopped,
+                                                         double* l1_delta, double* dangling_mass,
+                                                         cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(session, CUGRAPH_INVALID_INPUT, "session is NULL");
+    bool st = false;
+    session_status(*as<Session>(session), num_iterations, &st, l1_delta, dangling_mass);
+    if (stopped) *stopped = st ? TRUE : FALSE;
+  });
+}
+
+cugraph_error_code_t cugraph_amd_pagerank_session_result(cugraph_amd_pagerank_session_t* session,
+                                                         size_t max_iterations,
+                                                         cugraph_centrality_result_t** result,
+                                                         cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(session && result, CUGRAPH_INVALID_INPUT, "NULL argument");
+    *result = reinterpret_cast<cugraph_centrality_result_t*>(
+      session_result(*as<Session>(session), max_iterations));
+  });
+}
+
+cugraph_error_code_t cugraph_amd_pagerank_session_info(cugraph_amd_pagerank_session_t* session,
+                                                       int64_t info[8], cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(session && info, CUGRAPH_INVALID_INPUT, "NULL argument");
+    session_info(*as<Session>(session), info);
+  });
+}
+
+void cugraph_amd_pagerank_session_free(cugraph_amd_pagerank_session_t* session)
+{
+  session_destroy(as<Session>(session));
+}
+
+const char* cugraph_amd_version(void) { return "cugraph_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// Internal types shared by the translation units of libcugraph_amd_c.so.
+// Nothing here crosses the C ABI: the public view of every struct is an opaque pointer
+// (include/cugraph_amd_c.h), as in the reference (cpp/include/cugraph_c/graph.h:25-27).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cugraph_amd_c.h"
+
+namespace cga {
+
+// ---------------------------------------------------------------- errors
+struct Error {
+  std::string message;
+};
+
+struct Failure : std::runtime_error {
+  cugraph_error_code_t code;
+  Failure(cugraph_error_code_t c, std::string const& m) : std::runtime_error(m), code(c) {}
+};
+
+#define CGA_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess) {                                                                   \
+      throw cga::Failure(e__ == hipErrorOutOfMemory ? CUGRAPH_ALLOC_ERROR                     \
+                                                    : CUGRAPH_UNKNOWN_ERROR,                   \
+                         std::string("HIP error: ") + hipGetErrorString(e__) + " at " +        \
+                           __FILE__ + ":" + std::to_string(__LINE__));                         \
+    }                                                                                          \
+  } while (0)
+
+#define CGA_EXPECTS(cond, code, msg)                 \
+  do {                                               \
+    if (!(cond)) throw cga::Failure((code), (msg)); \
+  } while (0)
+
+// ---------------------------------------------------------------- handle / arrays
+struct Handle {
+  hipStream_t stream{nullptr};
+  bool owns_stream{false};
+  int device{0};
+  int comm_size{1};
+  int rank{0};
+};
+
+inline size_t dtype_size(cugraph_data_type_id_t t)
+{
+  switch (t) {
+    case INT32: return 4;
+    case INT64: return 8;
+    case FLOAT32: return 4;
+    case FLOAT64: return 8;
+    case SIZE_T: return 8;
+    default: return 0;
+  }
+}
+
+// non-owning {data, size, nbytes, type} -- reference: cpp/src/c_api/array.hpp:26-45
+struct ArrayView {
+  void* data{nullptr};
+  size_t size{0};
+  size_t nbytes{0};
+  cugraph_data_type_id_t type{INT32};
+};
+
+// owning device buffer -- reference: cpp/src/c_api/array.hpp:47-84
+struct Array {
+  void* data{nullptr};
+  size_t size{0};
+  size_t nbytes{0};
+  cugraph_data_type_id_t type{INT32};
+  ~Array()
+  {
+    if (data) (void)hipFree(data);
+  }
+};
+
+struct HostArrayView {
+  void* data{nullptr};
+  size_t size{0};
+  size_t nbytes{0};
+  cugraph_data_type_id_t type{INT32};
+};
+
+struct HostArray {
+  void* data{nullptr};
+  size_t size{0};
+  size_t nbytes{0};
+  cugraph_data_type_id_t type{INT32};
+  ~HostArray() { ::operator delete(data); }
+};
+
+// RAII device buffer for internal temporaries
+struct DevBuf {
+  void* p{nullptr};
+  size_t bytes{0};
+  DevBuf() = default;
+  explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(DevBuf const&)            = delete;
+  DevBuf& operator=(DevBuf const&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept
+  {
+    if (this != &o) {
+      release();
+      p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t n)
+  {
+    release();
+    bytes = n;
+    if (n) CGA_HIP(hipMalloc(&p, n));
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+  }
+  void* detach()
+  {
+    void* r = p;
+    p = nullptr; bytes = 0;
+    return r;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------- graph
+// Compressed sparse graph.  Majors are dst when store_transposed (CSC, the pull layout PageRank
+// wants), src otherwise.  Indices are always int32 internally (V < 2^31); offsets are int32 while
+// num_edges < 2^31, else int64 -- the same switch as cpp/src/c_api/graph_sg.cpp:568-572.
+struct PullPlan;  // pagerank.hip
+
+struct Graph {
+  cugraph_data_type_id_t vertex_type{INT32};  // type of the ids the caller handed over / gets back
+  cugraph_data_type_id_t edge_type{INT32};
+  cugraph_data_type_id_t weight_type{FLOAT32};  // FLOAT32 also for unweighted graphs (graph_sg.cpp:247)
+  bool store_transposed{false};
+  bool is_symmetric{false};
+  bool is_multigraph{false};
+  bool renumbered{false};
+
+  int64_t num_vertices{0};         // majors held here (SG: all vertices)
+  int64_t num_global_vertices{0};  // id space of the minors (== num_vertices on one GPU)
+  int64_t vertex_first{0};         // first global id of the local major range (1D partition)
+  int64_t num_edges{0};
+  bool off64{false};
+
+  void* offsets{nullptr};     // int32/int64 [num_vertices + 1]
+  int32_t* indices{nullptr};  // [num_edges]
+  void* weights{nullptr};     // float/double [num_edges] or nullptr
+  void* number_map{nullptr};  // internal id -> external id, vertex_type[num_vertices]; nullptr = identity
+
+  PullPlan* plan{nullptr};  // cached by the first PageRank call on this graph
+
+  ~Graph();
+};
+
+struct CentralityResult {
+  Array* vertex_ids{nullptr};
+  Array* values{nullptr};
+  size_t num_iterations{0};
+  bool converged{false};
+  ~CentralityResult()
+  {
+    delete vertex_ids;
+    delete values;
+  }
+};
+
+// ---------------------------------------------------------------- graph_build.hip
+struct CompressedOut {
+  DevBuf offsets;  // int32 or int64
+  DevBuf indices;  // int32
+  DevBuf weights;  // weight type or empty
+  bool off64{false};
+};
+
+// COO (majors, minors int32, already validated to lie in [0, n_major) x [0, n_minor)) -> compressed,
+// minors ascending inside each major, ties in input order.
+CompressedOut compress_coo(hipStream_t stream,
+                           int64_t n_major,
+                           int64_t n_minor,
+                           int64_t n_edges,
+                           int32_t const* majors,
+                           int32_t const* minors,
+                           void const* weights,
+                           size_t weight_size);
+
+// offsets -> one major id per edge (the inverse of the histogram+scan)
+void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,
+                    int64_t n_edges, int32_t* majors_out);
+
+// ids of any integer type -> int32, with range check; returns max id seen (or -1 if empty)
+int64_t narrow_ids(hipStream_t stream, void const* in, cugraph_data_type_id_t type, size_t n,
+                   int32_t* out, int64_t* min_out);
+
+void fill_sequence(hipStream_t stream, void* out, cugraph_data_type_id_t type, size_t n,
+                   int64_t first);
+
+void transpose_graph(Handle const& h, Graph& g);
+
+// out[i] = in[i] - shift  /  out[i] = (int64) in[i]
+void shift_ids(hipStream_t stream, int32_t const* in, int32_t* out, int64_t n, int64_t shift);
+void widen_ids(hipStream_t stream, int32_t const* in, int64_t* out, int64_t n);
+
+// ---------------------------------------------------------------- pagerank.hip
+struct PagerankArgs {
+  ArrayView const* pre_vertices{nullptr};
+  ArrayView const* pre_sums{nullptr};
+  ArrayView const* guess_vertices{nullptr};
+  ArrayView const* guess_values{nullptr};
+  ArrayView const* pers_vertices{nullptr};
+  ArrayView const* pers_values{nullptr};
+  double alpha{0.85};
+  double epsilon{1e-6};
+  size_t max_iterations{100};
+  bool do_expensive_check{false};
+};
+
+CentralityResult* run_pagerank(Handle const& h, Graph& g, PagerankArgs const& a);
+void destroy_plan(PullPlan* p);
+
+// ---------------------------------------------------------------- rmat.hip
+void rmat_generate(hipStream_t stream, int scale, uint64_t first, uint64_t count, uint64_t seed,
+                   uint32_t t_ab, uint32_t t_a, uint32_t t_c, int scramble, int32_t* src,
+                   int32_t* dst);
+void rmat_weights(hipStream_t stream, uint64_t first, uint64_t count, uint64_t seed, void* w,
+                  bool f64);
+
+}  // namespace cga

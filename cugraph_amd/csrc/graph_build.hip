@@ -1,0 +1,673 @@
+// COO -> compressed sparse (CSC for the pull layout) on gfx950.
+//
+// Replaces cugraph::detail::sort_and_compress_edgelist / compute_sparse_offsets
+// (reference: cpp/src/structure/detail/structure_utils.cuh:54-88, 144-296).  The reference
+// sorts the whole (major, minor) edge list; here the layout is produced by
+//   1. degree histogram of the majors          (hist_kernel)
+//   2. exclusive scan -> offsets               (scan_* kernels)
+//   3. scatter of the minors into their column (scatter_kernel, arrival order arbitrary)
+//   4. ordering INSIDE each column by (minor, input position), degree-bucketed:
+//        deg <= 16   : 16-lane groups, register bitonic network over DPP/shuffles
+//        deg <= 64   : one wave64 per column, same network
+//        deg <= 8192 : one workgroup per column, LDS bitonic
+//        larger      : one 1024-thread workgroup per column, LSD radix through a scratch copy
+// Step 4 makes the result independent of the atomic arrival order of step 3, and equal to a
+// stable (major, minor)-lexicographic sort of the input -- the definition of the reference CSC.
+// For weighted graphs the sort key carries the input edge position in its low 32 bits, so
+// parallel edges keep input order and the weights are gathered once at the end.
+//
+// All of this is HBM-bound integer work; no MFMA.  Algorithmic bytes:
+//   E*(4*4 + 2*b_w) + 3*(V+1)*b_off  (+ 2*E*(4+b_w) for the ordering pass).
+#include "common.hpp"
+
+namespace cga {
+
+namespace {
+
+constexpr int kThreads   = 256;
+constexpr int kMaxBlocks = 256 * 16;  // 256 CUs x 16 resident 256-thread blocks: grid-stride beyond
+
+inline int grid_for(int64_t work_items, int threads = kThreads)
+{
+  int64_t b = (work_items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return static_cast<int>(b);
+}
+
+// ------------------------------------------------------------------ id narrowing
+template <typename InT>
+__global__ void narrow_kernel(InT const* __restrict__ in, size_t n, int32_t* __restrict__ out,
+                              long long* __restrict__ minmax /* [0]=min [1]=max */)
+{
+  long long lo = 0x7fffffffffffffffLL, hi = -1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    long long v = static_cast<long long>(in[i]);
+    out[i]      = static_cast<int32_t>(v);
+    lo          = v < lo ? v : lo;
+    hi          = v > hi ? v : hi;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(minmax, lo);
+    atomicMax(minmax + 1, hi);
+  }
+}
+
+__global__ void shift_kernel(int32_t const* in, int32_t* out, int64_t n, int32_t shift)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[i] - shift;
+}
+
+__global__ void widen_kernel(int32_t const* in, int64_t* out, int64_t n)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[i];
+}
+
+template <typename OutT>
+__global__ void sequence_kernel(OutT* out, size_t n, long long first)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = static_cast<OutT>(first + (long long)i);
+}
+
+// ------------------------------------------------------------------ 1. histogram
+__global__ void hist_kernel(int32_t const* __restrict__ keys, int64_t n,
+                            unsigned int* __restrict__ counts)
+{
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+    atomicAdd(&counts[keys[i]], 1u);
+}
+
+// ------------------------------------------------------------------ 2. exclusive scan
+constexpr int kScanItems = 16;                     // per thread
+constexpr int kScanTile  = kThreads * kScanItems;  // 4096 per block
+
+__device__ inline unsigned long long block_reduce_u64(unsigned long long v,
+                                                      unsigned long long* lds /* [4] */)
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long t = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ void scan_tile_sums_kernel(unsigned int const* __restrict__ counts, int64_t n,
+                                      unsigned long long* __restrict__ tile_sums)
+{
+  __shared__ unsigned long long lds[4];
+  int64_t base = (int64_t)blockIdx.x * kScanTile;
+  unsigned long long s = 0;
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = base + (int64_t)k * kThreads + threadIdx.x;
+    if (i < n) s += counts[i];
+  }
+  s = block_reduce_u64(s, lds);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = s;
+}
+
+// single workgroup: in-place exclusive scan of the tile sums
+__global__ void scan_tile_prefix_kernel(unsigned long long* __restrict__ tile_sums, int64_t n_tiles)
+{
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t base = 0; base < n_tiles; base += blockDim.x) {
+    int64_t i            = base + threadIdx.x;
+    unsigned long long v = i < n_tiles ? tile_sums[i] : 0ull;
+    unsigned long long inc = v;  // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned long long before = carry;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    if (i < n_tiles) tile_sums[i] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry = before + inc;
+    __syncthreads();
+  }
+}
+
+template <typename OffT>
+__global__ void scan_write_kernel(unsigned int const* __restrict__ counts, int64_t n,
+                                  unsigned long long const* __restrict__ tile_prefix,
+                                  OffT* __restrict__ offsets /* [n+1] */)
+{
+  // thread t owns items [t*16, t*16+16) of the tile: sequential local scan + wave/block prefix
+  __shared__ unsigned long long wave_tot[4];
+  int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  unsigned int c[kScanItems];
+  unsigned long long s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = base + k;
+    c[k]      = i < n ? counts[i] : 0u;
+    s += c[k];
+  }
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned long long t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  unsigned long long run = tile_prefix[blockIdx.x] + inc - s;
+  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int64_t i = base + k;
+    if (i < n) offsets[i] = static_cast<OffT>(run);
+    run += c[k];
+    if (i == n - 1) offsets[n] = static_cast<OffT>(run);
+  }
+  if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+}
+
+// ------------------------------------------------------------------ 3. scatter
+template <typename OffT, typename KeyT>
+__global__ void scatter_kernel(int32_t const* __restrict__ majors,
+                               int32_t const* __restrict__ minors, int64_t n,
+                               OffT const* __restrict__ offsets,
+                               unsigned int* __restrict__ cursor, KeyT* __restrict__ keys)
+{
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += stride) {
+    int32_t m        = majors[e];
+    unsigned int pos = atomicAdd(&cursor[m], 1u);
+    KeyT k;
+    if constexpr (sizeof(KeyT) == 8) {
+      k = (static_cast<KeyT>(static_cast<uint32_t>(minors[e])) << 32) |
+          static_cast<KeyT>(static_cast<uint32_t>(e));
+    } else {
+      k = static_cast<KeyT>(minors[e]);
+    }
+    keys[offsets[m] + pos] = k;
+  }
+}
+
+// ------------------------------------------------------------------ 4. per-column ordering
+template <typename KeyT>
+__device__ inline KeyT key_max()
+{
+  return ~static_cast<KeyT>(0);
+}
+
+// G lanes per column (G = 16 or 64); columns with lo < deg <= G are sorted, the rest skipped.
+template <typename OffT, typename KeyT, int G>
+__global__ void sort_small_kernel(OffT const* __restrict__ offsets, KeyT* __restrict__ keys,
+                                  int64_t n_major, int lo)
+{
+  int lane       = threadIdx.x & (G - 1);
+  int64_t group  = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
+  for (int64_t v = group; v < n_major; v += groups) {
+    OffT b      = offsets[v];
+    int64_t deg = static_cast<int64_t>(offsets[v + 1] - b);
+    if (deg <= lo || deg > G) continue;  // uniform over the G lanes of a group
+    KeyT k = lane < deg ? keys[b + lane] : key_max<KeyT>();
+#pragma unroll
+    for (int size = 2; size <= G; size <<= 1) {
+#pragma unroll
+      for (int j = size >> 1; j > 0; j >>= 1) {
+        KeyT o     = __shfl_xor(k, j, G);
+        bool up    = (lane & size) == 0;
+        bool lower = (lane & j) == 0;
+        KeyT mn = k < o ? k : o, mx = k < o ? o : k;
+        k = (lower == up) ? mn : mx;
+      }
+    }
+    if (lane < deg) keys[b + lane] = k;
+  }
+}
+
+constexpr int kMedCap = 8192;  // keys per workgroup-sorted column (64 KiB of LDS at 8-byte keys)
+
+template <typename OffT>
+__global__ void classify_columns_kernel(OffT const* __restrict__ offsets, int64_t n_major,
+                                        int32_t* __restrict__ med_list,
+                                        int32_t* __restrict__ big_list,
+                                        unsigned int* __restrict__ n_lists /* [2] */)
+{
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_major; v += stride) {
+    int64_t deg = static_cast<int64_t>(offsets[v + 1] - offsets[v]);
+    if (deg > 64) {
+      if (deg <= kMedCap)
+        med_list[atomicAdd(&n_lists[0], 1u)] = static_cast<int32_t>(v);
+      else
+        big_list[atomicAdd(&n_lists[1], 1u)] = static_cast<int32_t>(v);
+    }
+  }
+}
+
+template <typename OffT, typename KeyT>
+__global__ __launch_bounds__(256) void sort_medium_kernel(OffT const* __restrict__ offsets,
+                                                          KeyT* __restrict__ keys,
+                                                          int32_t const* __restrict__ list,
+                                                          unsigned int const* __restrict__ n_list)
+{
+  __shared__ KeyT lds[kMedCap];
+  unsigned int n_cols = *n_list;
+  for (unsigned int c = blockIdx.x; c < n_cols; c += gridDim.x) {
+    int32_t v = list[c];
+    OffT b    = offsets[v];
+    int deg   = static_cast<int>(offsets[v + 1] - b);
+    int P     = 128;
+    while (P < deg) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) lds[i] = i < deg ? keys[b + i] : key_max<KeyT>();
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int j = size >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+          // t-th compare-exchange pair of this stage: i has bit j clear
+          int i   = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          int p   = i | j;
+          KeyT a = lds[i], d = lds[p];
+          bool up = (i & size) == 0;
+          if ((a > d) == up) {
+            lds[i] = d;
+            lds[p] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = threadIdx.x; i < deg; i += blockDim.x) keys[b + i] = lds[i];
+    __syncthreads();
+  }
+}
+
+struct RadixPasses {
+  int n;
+  int shift[8];
+};
+
+// One 1024-thread workgroup per column; stable LSD radix, 8 bits per pass, ping-pong between the
+// column's slice of `keys` and the same slice of `tmp`.
+template <typename OffT, typename KeyT>
+__global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__ offsets,
+                                                        KeyT* __restrict__ keys,
+                                                        KeyT* __restrict__ tmp,
+                                                        int32_t const* __restrict__ list,
+                                                        unsigned int const* __restrict__ n_list,
+                                                        RadixPasses passes)
+{
+  __shared__ unsigned int base[256];
+  __shared__ unsigned int wave_cnt[16][256];
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  unsigned int n_cols        = *n_list;
+  for (unsigned int c = blockIdx.x; c < n_cols; c += gridDim.x) {
+    int32_t v   = list[c];
+    OffT b      = offsets[v];
+    int64_t deg = static_cast<int64_t>(offsets[v + 1] - b);
+    KeyT* in    = keys + b;
+    KeyT* out   = tmp + b;
+    for (int p = 0; p < passes.n; ++p) {
+      int sh = passes.shift[p];
+      if (threadIdx.x < 256) base[threadIdx.x] = 0;
+      __syncthreads();
+      for (int64_t i = threadIdx.x; i < deg; i += blockDim.x)
+        atomicAdd(&base[(unsigned int)(in[i] >> sh) & 255u], 1u);
+      __syncthreads();
+      if (wave == 0) {  // exclusive scan of 256 counters by one wave, 4 per lane
+        unsigned int c0 = base[lane * 4], c1 = base[lane * 4 + 1], c2 = base[lane * 4 + 2],
+                     c3 = base[lane * 4 + 3];
+        unsigned int s  = c0 + c1 + c2 + c3, inc = s;
+        for (int o = 1; o < 64; o <<= 1) {
+          unsigned int t = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += t;
+        }
+        unsigned int ex    = inc - s;
+        base[lane * 4]     = ex;
+        base[lane * 4 + 1] = ex + c0;
+        base[lane * 4 + 2] = ex + c0 + c1;
+        base[lane * 4 + 3] = ex + c0 + c1 + c2;
+      }
+      __syncthreads();
+      for (int64_t chunk = 0; chunk < deg; chunk += blockDim.x) {
+        for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) (&wave_cnt[0][0])[i] = 0;
+        __syncthreads();
+        int64_t i  = chunk + threadIdx.x;
+        bool valid = i < deg;
+        KeyT k     = valid ? in[i] : 0;
+        unsigned int d = (unsigned int)(k >> sh) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          unsigned long long bal = __ballot(valid && ((d >> bit) & 1u));
+          m &= ((d >> bit) & 1u) ? bal : ~bal;
+        }
+        unsigned int rank = __popcll(m & lt_mask);
+        if (valid && rank == 0) wave_cnt[wave][d] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x < 256) {
+          unsigned int run = base[threadIdx.x];
+          for (int w = 0; w < 16; ++w) {
+            unsigned int t            = wave_cnt[w][threadIdx.x];
+            wave_cnt[w][threadIdx.x] = run;
+            run += t;
+          }
+          base[threadIdx.x] = run;
+        }
+        __syncthreads();
+        if (valid) out[wave_cnt[wave][d] + rank] = k;
+        __syncthreads();
+      }
+      // the next pass reads what this one wrote (same workgroup, global memory)
+      __threadfence_block();
+      KeyT* t = in;
+      in      = out;
+      out     = t;
+    }
+    if (passes.n & 1) {  // result sits in tmp
+      for (int64_t i = threadIdx.x; i < deg; i += blockDim.x) out[i] = in[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ weighted epilogue
+template <typename WT>
+__global__ void unpack_weighted_kernel(unsigned long long const* __restrict__ keys, int64_t n,
+                                       WT const* __restrict__ w_in, int32_t* __restrict__ indices,
+                                       WT* __restrict__ w_out)
+{
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned long long k = keys[i];
+    indices[i]           = static_cast<int32_t>(k >> 32);
+    w_out[i]             = w_in[static_cast<uint32_t>(k)];
+  }
+}
+
+template <typename OffT>
+__global__ void expand_offsets_kernel(OffT const* __restrict__ offsets, int64_t n_major,
+                                      int64_t n_edges, int32_t* __restrict__ majors)
+{
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_edges; e += stride) {
+    // last major m with offsets[m] <= e
+    int64_t lo = 0, hi = n_major;  // invariant: offsets[lo] <= e < offsets[hi]
+    while (hi - lo > 1) {
+      int64_t mid = (lo + hi) >> 1;
+      if (static_cast<int64_t>(offsets[mid]) <= e)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    majors[e] = static_cast<int32_t>(lo);
+  }
+}
+
+inline int bit_width_u64(uint64_t v)
+{
+  int b = 0;
+  while (v) { ++b; v >>= 1; }
+  return b;
+}
+
+template <typename OffT, typename KeyT>
+void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t n_major,
+                   int64_t n_minor, int64_t n_edges)
+{
+  if (n_edges < 2) return;
+  hipLaunchKernelGGL((sort_small_kernel<OffT, KeyT, 16>), dim3(grid_for(n_major * 16)), dim3(kThreads),
+                     0, stream, offsets, keys, n_major, 1);
+  hipLaunchKernelGGL((sort_small_kernel<OffT, KeyT, 64>), dim3(grid_for(n_major * 64)), dim3(kThreads),
+                     0, stream, offsets, keys, n_major, 16);
+  // lists of the longer columns
+  int64_t max_long = n_edges / 65 + 1;
+  if (max_long > n_major) max_long = n_major;
+  DevBuf med(max_long * sizeof(int32_t)), big(max_long * sizeof(int32_t)), counts(2 * sizeof(unsigned int));
+  CGA_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned int), stream));
+  hipLaunchKernelGGL((classify_columns_kernel<OffT>), dim3(grid_for(n_major)), dim3(kThreads), 0,
+                     stream, offsets, n_major, med.as<int32_t>(), big.as<int32_t>(),
+                     counts.as<unsigned int>());
+  unsigned int h_counts[2];
+  CGA_HIP(hipMemcpyAsync(h_counts, counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  if (h_counts[0] > 0) {
+    int grid = h_counts[0] < 2048u ? (int)h_counts[0] : 2048;
+    hipLaunchKernelGGL((sort_medium_kernel<OffT, KeyT>), dim3(grid), dim3(256), 0, stream, offsets,
+                       keys, med.as<int32_t>(), counts.as<unsigned int>());
+  }
+  DevBuf tmp;
+  if (h_counts[1] > 0) {
+    RadixPasses passes{};
+    if constexpr (sizeof(KeyT) == 8) {
+      int be = bit_width_u64(static_cast<uint64_t>(n_edges - 1));
+      int bv = bit_width_u64(static_cast<uint64_t>(n_minor > 0 ? n_minor - 1 : 0));
+      for (int s = 0; s < be; s += 8) passes.shift[passes.n++] = s;
+      for (int s = 0; s < bv; s += 8) passes.shift[passes.n++] = 32 + s;
+    } else {
+      int bv = bit_width_u64(static_cast<uint64_t>(n_minor > 0 ? n_minor - 1 : 0));
+      for (int s = 0; s < bv; s += 8) passes.shift[passes.n++] = s;
+    }
+    if (passes.n > 0) {
+      tmp.alloc(static_cast<size_t>(n_edges) * sizeof(KeyT));
+      int grid = h_counts[1] < 1024u ? (int)h_counts[1] : 1024;
+      hipLaunchKernelGGL((sort_big_kernel<OffT, KeyT>), dim3(grid), dim3(1024), 0, stream, offsets,
+                         keys, tmp.as<KeyT>(), big.as<int32_t>(), counts.as<unsigned int>() + 1,
+                         passes);
+    }
+  }
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));  // temporaries die here
+}
+
+template <typename OffT>
+CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
+                            int32_t const* majors, int32_t const* minors, void const* weights,
+                            size_t weight_size)
+{
+  CompressedOut out;
+  out.off64 = sizeof(OffT) == 8;
+  out.offsets.alloc(static_cast<size_t>(n_major + 1) * sizeof(OffT));
+  out.indices.alloc(static_cast<size_t>(n_edges > 0 ? n_edges : 1) * sizeof(int32_t));
+  if (weights) out.weights.alloc(static_cast<size_t>(n_edges > 0 ? n_edges : 1) * weight_size);
+
+  DevBuf counts(static_cast<size_t>(n_major > 0 ? n_major : 1) * sizeof(unsigned int));
+  CGA_HIP(hipMemsetAsync(counts.p, 0, counts.bytes, stream));
+  if (n_edges > 0)
+    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n_edges)), dim3(kThreads), 0, stream, majors,
+                       n_edges, counts.as<unsigned int>());
+
+  int64_t n_tiles = (n_major + kScanTile - 1) / kScanTile;
+  if (n_tiles < 1) n_tiles = 1;
+  DevBuf tile_sums(static_cast<size_t>(n_tiles) * sizeof(unsigned long long));
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, stream,
+                     counts.as<unsigned int>(), n_major, tile_sums.as<unsigned long long>());
+  hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, stream,
+                     tile_sums.as<unsigned long long>(), n_tiles);
+  hipLaunchKernelGGL((scan_write_kernel<OffT>), dim3((unsigned)n_tiles), dim3(kThreads), 0, stream,
+                     counts.as<unsigned int>(), n_major, tile_sums.as<unsigned long long>(),
+                     out.offsets.as<OffT>());
+
+  if (n_edges > 0) {
+    CGA_HIP(hipMemsetAsync(counts.p, 0, counts.bytes, stream));
+    if (weights) {
+      CGA_EXPECTS(n_edges <= 0xffffffffLL, CUGRAPH_NOT_IMPLEMENTED,
+                  "weighted graphs with 2^32 or more edges per GPU are not supported");
+      DevBuf keys(static_cast<size_t>(n_edges) * sizeof(unsigned long long));
+      hipLaunchKernelGGL((scatter_kernel<OffT, unsigned long long>), dim3(grid_for(n_edges)),
+                         dim3(kThreads), 0, stream, majors, minors, n_edges, out.offsets.as<OffT>(),
+                         counts.as<unsigned int>(), keys.as<unsigned long long>());
+      order_columns<OffT, unsigned long long>(stream, out.offsets.as<OffT>(),
+                                              keys.as<unsigned long long>(), n_major, n_minor,
+                                              n_edges);
+      if (weight_size == 4)
+        hipLaunchKernelGGL((unpack_weighted_kernel<float>), dim3(grid_for(n_edges)), dim3(kThreads),
+                           0, stream, keys.as<unsigned long long>(), n_edges,
+                           static_cast<float const*>(weights), out.indices.as<int32_t>(),
+                           out.weights.as<float>());
+      else
+        hipLaunchKernelGGL((unpack_weighted_kernel<double>), dim3(grid_for(n_edges)),
+                           dim3(kThreads), 0, stream, keys.as<unsigned long long>(), n_edges,
+                           static_cast<double const*>(weights), out.indices.as<int32_t>(),
+                           out.weights.as<double>());
+      CGA_HIP(hipGetLastError());
+      CGA_HIP(hipStreamSynchronize(stream));
+    } else {
+      hipLaunchKernelGGL((scatter_kernel<OffT, uint32_t>), dim3(grid_for(n_edges)), dim3(kThreads),
+                         0, stream, majors, minors, n_edges, out.offsets.as<OffT>(),
+                         counts.as<unsigned int>(), out.indices.as<uint32_t>());
+      order_columns<OffT, uint32_t>(stream, out.offsets.as<OffT>(), out.indices.as<uint32_t>(),
+                                    n_major, n_minor, n_edges);
+    }
+  }
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
+  return out;
+}
+
+}  // namespace
+
+CompressedOut compress_coo(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
+                           int32_t const* majors, int32_t const* minors, void const* weights,
+                           size_t weight_size)
+{
+  // same switch as the reference's edge_t choice (cpp/src/c_api/graph_sg.cpp:568-572)
+  if (n_edges < 0x7fffffffLL)
+    return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
+                                  weight_size);
+  return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
+                                weight_size);
+}
+
+// exclusive scan of 32-bit counts into 64-bit positions, out[n] = total (stream compaction helper)
+void exclusive_scan_u32_to_i64(hipStream_t stream, unsigned int const* counts, int64_t n,
+                               int64_t* out)
+{
+  int64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+  if (n_tiles < 1) n_tiles = 1;
+  DevBuf tile_sums(static_cast<size_t>(n_tiles) * sizeof(unsigned long long));
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, stream,
+                     counts, n, tile_sums.as<unsigned long long>());
+  hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, stream,
+                     tile_sums.as<unsigned long long>(), n_tiles);
+  hipLaunchKernelGGL((scan_write_kernel<int64_t>), dim3((unsigned)n_tiles), dim3(kThreads), 0,
+                     stream, counts, n, tile_sums.as<unsigned long long>(), out);
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));  // tile_sums dies here
+}
+
+// In-place re-orientation: CSR (majors = sources) <-> CSC (majors = destinations).  The reference
+// does the same to the caller's graph when PageRank meets store_transposed == false
+// (cpp/src/c_api/pagerank.cpp:105-110, cpp/src/c_api/graph.hpp:57-123).
+void transpose_graph(Handle const& h, Graph& g)
+{
+  CGA_EXPECTS(g.num_global_vertices == g.num_vertices, CUGRAPH_NOT_IMPLEMENTED,
+              "transposing a partitioned graph is not supported");
+  hipStream_t stream = h.stream;
+  DevBuf old_majors(static_cast<size_t>(g.num_edges > 0 ? g.num_edges : 1) * sizeof(int32_t));
+  expand_offsets(stream, g.offsets, g.off64, g.num_vertices, g.num_edges, old_majors.as<int32_t>());
+  size_t wsize      = g.weights ? dtype_size(g.weight_type) : 0;
+  CompressedOut out = compress_coo(stream, g.num_vertices, g.num_vertices, g.num_edges, g.indices,
+                                   old_majors.as<int32_t>(), g.weights, wsize);
+  (void)hipFree(g.offsets);
+  (void)hipFree(g.indices);
+  if (g.weights) (void)hipFree(g.weights);
+  g.off64   = out.off64;
+  g.offsets = out.offsets.detach();
+  g.indices = static_cast<int32_t*>(out.indices.detach());
+  g.weights = out.weights.p ? out.weights.detach() : nullptr;
+  g.store_transposed = !g.store_transposed;
+  if (g.plan) {
+    destroy_plan(g.plan);
+    g.plan = nullptr;
+  }
+}
+
+Graph::~Graph()
+{
+  if (offsets) (void)hipFree(offsets);
+  if (indices) (void)hipFree(indices);
+  if (weights) (void)hipFree(weights);
+  if (number_map) (void)hipFree(number_map);
+  if (plan) destroy_plan(plan);
+}
+
+void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,
+                    int64_t n_edges, int32_t* majors_out)
+{
+  if (n_edges == 0) return;
+  if (off64)
+    hipLaunchKernelGGL((expand_offsets_kernel<int64_t>), dim3(grid_for(n_edges)), dim3(kThreads), 0,
+                       stream, static_cast<int64_t const*>(offsets), n_major, n_edges, majors_out);
+  else
+    hipLaunchKernelGGL((expand_offsets_kernel<int32_t>), dim3(grid_for(n_edges)), dim3(kThreads), 0,
+                       stream, static_cast<int32_t const*>(offsets), n_major, n_edges, majors_out);
+  CGA_HIP(hipGetLastError());
+}
+
+int64_t narrow_ids(hipStream_t stream, void const* in, cugraph_data_type_id_t type, size_t n,
+                   int32_t* out, int64_t* min_out)
+{
+  DevBuf mm(2 * sizeof(long long));
+  long long init[2] = {0x7fffffffffffffffLL, -1};
+  CGA_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  if (n > 0) {
+    if (type == INT32)
+      hipLaunchKernelGGL((narrow_kernel<int32_t>), dim3(grid_for((int64_t)n)), dim3(kThreads), 0,
+                         stream, static_cast<int32_t const*>(in), n, out, mm.as<long long>());
+    else
+      hipLaunchKernelGGL((narrow_kernel<int64_t>), dim3(grid_for((int64_t)n)), dim3(kThreads), 0,
+                         stream, static_cast<int64_t const*>(in), n, out, mm.as<long long>());
+    CGA_HIP(hipGetLastError());
+  }
+  long long res[2];
+  CGA_HIP(hipMemcpyAsync(res, mm.p, sizeof(res), hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  if (min_out) *min_out = res[0];
+  return res[1];
+}
+
+void shift_ids(hipStream_t stream, int32_t const* in, int32_t* out, int64_t n, int64_t shift)
+{
+  if (n == 0) return;
+  hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, in, out, n,
+                     static_cast<int32_t>(shift));
+  CGA_HIP(hipGetLastError());
+}
+
+void widen_ids(hipStream_t stream, int32_t const* in, int64_t* out, int64_t n)
+{
+  if (n == 0) return;
+  hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, in, out, n);
+  CGA_HIP(hipGetLastError());
+}
+
+void fill_sequence(hipStream_t stream, void* out, cugraph_data_type_id_t type, size_t n,
+                   int64_t first)
+{
+  if (n == 0) return;
+  if (type == INT32)
+    hipLaunchKernelGGL((sequence_kernel<int32_t>), dim3(grid_for((int64_t)n)), dim3(kThreads), 0,
+                       stream, static_cast<int32_t*>(out), n, (long long)first);
+  else
+    hipLaunchKernelGGL((sequence_kernel<int64_t>), dim3(grid_for((int64_t)n)), dim3(kThreads), 0,
+                       stream, static_cast<int64_t*>(out), n, (long long)first);
+  CGA_HIP(hipGetLastError());
+}
+
+}  // namespace cga

@@ -1,0 +1,358 @@
+/*
+ * cugraph_amd_c.h -- C ABI of libcugraph_amd_c.so, the MI355X-native drop-in for the PageRank
+ * path of libcugraph_c.
+ *
+ * Part 1 re-declares, with identical names, argument order and ownership rules, the subset of
+ * the reference's C API that pylibcugraph binds for `pagerank` / `personalized_pagerank` /
+ * `SGGraph` / `ResourceHandle` (each block cites the reference header it replaces; paths are
+ * relative to the reference tree).  A pylibcugraph built against these symbols needs no source
+ * change for this path -- see INTEGRATION.md.
+ *
+ * Part 2 (prefix cugraph_amd_) has no counterpart in the reference: R-MAT generation for the
+ * benchmark, read-only access to the compressed graph for parity tests, a 1D-partitioned local
+ * graph, and a step-wise PageRank session used by the multi-GPU driver and bench.py.
+ *
+ * Conventions (same as the reference, cpp/src/c_api/utils.hpp:23-59): no exception crosses the
+ * ABI; every fallible call returns a cugraph_error_code_t and, on failure, allocates *error
+ * (free with cugraph_error_free); *error is NULL on success.  All pointers inside views are
+ * device pointers valid on the handle's device.  Calls are synchronous with respect to the
+ * handle's HIP stream unless stated otherwise; one handle per host thread / GPU.
+ */
+#ifndef CUGRAPH_AMD_C_H
+#define CUGRAPH_AMD_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================== */
+/* Part 1 -- the reference's own entry points for this path               */
+/* ===================================================================== */
+
+/* ---- cpp/include/cugraph_c/error.h:25-52 ---- */
+typedef enum cugraph_error_code_ {
+  CUGRAPH_SUCCESS = 0,
+  CUGRAPH_UNKNOWN_ERROR,
+  CUGRAPH_INVALID_HANDLE,
+  CUGRAPH_ALLOC_ERROR,
+  CUGRAPH_INVALID_INPUT,
+  CUGRAPH_NOT_IMPLEMENTED,
+  CUGRAPH_UNSUPPORTED_TYPE_COMBINATION
+} cugraph_error_code_t;
+
+typedef struct cugraph_error_ { int32_t align_; } cugraph_error_t;
+
+const char* cugraph_error_message(const cugraph_error_t* error); /* error.h:45 */
+void cugraph_error_free(cugraph_error_t* error);                 /* error.h:52 */
+
+/* ---- cpp/include/cugraph_c/resource_handle.h:28-89 ---- */
+typedef enum bool_ { FALSE = 0, TRUE = 1 } bool_t;
+typedef int8_t byte_t;
+typedef enum data_type_id_ { INT32 = 0, INT64, FLOAT32, FLOAT64, SIZE_T, NTYPES } data_type_id_t;
+typedef data_type_id_t cugraph_data_type_id_t;
+
+typedef struct cugraph_resource_handle_ { int32_t align_; } cugraph_resource_handle_t;
+
+/* resource_handle.h:58.  The reference takes a raft::handle_t*; here the argument must be NULL
+ * (the library makes a handle on the current HIP device and the NULL stream).  Use
+ * cugraph_amd_create_resource_handle (part 2) to bind a stream or a partition rank. */
+cugraph_resource_handle_t* cugraph_create_resource_handle(void* raft_handle);
+int cugraph_resource_handle_get_comm_size(const cugraph_resource_handle_t* handle); /* :70 */
+int cugraph_resource_handle_get_rank(const cugraph_resource_handle_t* handle);      /* :82 */
+void cugraph_free_resource_handle(cugraph_resource_handle_t* handle);               /* :89 */
+
+/* ---- cpp/include/cugraph_c/array.h:25-331 ---- */
+typedef struct { int32_t align_; } cugraph_type_erased_device_array_t;
+typedef struct { int32_t align_; } cugraph_type_erased_device_array_view_t;
+typedef struct { int32_t align_; } cugraph_type_erased_host_array_t;
+typedef struct { int32_t align_; } cugraph_type_erased_host_array_view_t;
+
+cugraph_error_code_t cugraph_type_erased_device_array_create( /* array.h:52 */
+  const cugraph_resource_handle_t* handle, size_t n_elems, cugraph_data_type_id_t dtype,
+  cugraph_type_erased_device_array_t** array, cugraph_error_t** error);
+cugraph_error_code_t cugraph_type_erased_device_array_create_from_view( /* array.h:71 */
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* view,
+  cugraph_type_erased_device_array_t** array, cugraph_error_t** error);
+void cugraph_type_erased_device_array_free(cugraph_type_erased_device_array_t* p); /* :82 */
+cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view(    /* :105 */
+  cugraph_type_erased_device_array_t* array);
+cugraph_error_code_t cugraph_type_erased_device_array_view_as_type( /* array.h:126 */
+  cugraph_type_erased_device_array_t* array, cugraph_data_type_id_t dtype,
+  cugraph_type_erased_device_array_view_t** result_view, cugraph_error_t** error);
+/* array.h:141 -- views are heap objects the caller frees; they never own the memory */
+cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view_create(
+  void* pointer, size_t n_elems, cugraph_data_type_id_t dtype);
+void cugraph_type_erased_device_array_view_free(cugraph_type_erased_device_array_view_t* p);
+size_t cugraph_type_erased_device_array_view_size(const cugraph_type_erased_device_array_view_t* p);
+cugraph_data_type_id_t cugraph_type_erased_device_array_view_type(
+  const cugraph_type_erased_device_array_view_t* p);
+const void* cugraph_type_erased_device_array_view_pointer(
+  const cugraph_type_erased_device_array_view_t* p);
+
+cugraph_error_code_t cugraph_type_erased_host_array_create( /* array.h:188 */
+  const cugraph_resource_handle_t* handle, size_t n_elems, cugraph_data_type_id_t dtype,
+  cugraph_type_erased_host_array_t** array, cugraph_error_t** error);
+void cugraph_type_erased_host_array_free(cugraph_type_erased_host_array_t* p);
+cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view(
+  cugraph_type_erased_host_array_t* array);
+cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view_create(
+  void* pointer, size_t n_elems, cugraph_data_type_id_t dtype);
+void cugraph_type_erased_host_array_view_free(cugraph_type_erased_host_array_view_t* p);
+size_t cugraph_type_erased_host_array_size(const cugraph_type_erased_host_array_view_t* p);
+cugraph_data_type_id_t cugraph_type_erased_host_array_type(
+  const cugraph_type_erased_host_array_view_t* p);
+void* cugraph_type_erased_host_array_pointer(const cugraph_type_erased_host_array_view_t* p);
+cugraph_error_code_t cugraph_type_erased_host_array_view_copy( /* array.h:279 */
+  const cugraph_resource_handle_t* handle, cugraph_type_erased_host_array_view_t* dst,
+  const cugraph_type_erased_host_array_view_t* src, cugraph_error_t** error);
+
+cugraph_error_code_t cugraph_type_erased_device_array_view_copy_from_host( /* array.h:295 */
+  const cugraph_resource_handle_t* handle, cugraph_type_erased_device_array_view_t* dst,
+  const byte_t* h_src, cugraph_error_t** error);
+cugraph_error_code_t cugraph_type_erased_device_array_view_copy_to_host( /* array.h:311 */
+  const cugraph_resource_handle_t* handle, byte_t* h_dst,
+  const cugraph_type_erased_device_array_view_t* src, cugraph_error_t** error);
+cugraph_error_code_t cugraph_type_erased_device_array_view_copy( /* array.h:327 */
+  const cugraph_resource_handle_t* handle, cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* src, cugraph_error_t** error);
+
+/* ---- cpp/include/cugraph_c/graph.h:25-36, 66-131, 161-213, 321-330 ---- */
+typedef struct { int32_t align_; } cugraph_graph_t;
+typedef struct {
+  bool_t is_symmetric;
+  bool_t is_multigraph;
+} cugraph_graph_properties_t;
+
+/* graph.h:116 (impl cpp/src/c_api/graph_sg.cpp:508-633).  Inputs are copied; the caller keeps
+ * its arrays.  edge_ids / edge_type_ids are accepted for signature compatibility and ignored
+ * (PageRank never reads them).  renumber=TRUE relabels vertices by descending in-degree and the
+ * result carries the external ids (renumber_edgelist_impl.cuh:238-607). */
+cugraph_error_code_t cugraph_graph_create_sg(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* vertices,
+  const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t do_expensive_check,
+  cugraph_graph_t** graph, cugraph_error_t** error);
+
+/* graph.h:66 (deprecated spelling, still what cpp/tests/c_api/test_utils.cpp:101 calls) */
+cugraph_error_code_t cugraph_sg_graph_create(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+
+/* graph.h:201 / :161 (impl graph_sg.cpp:666-789): offsets are over sources (CSR). */
+cugraph_error_code_t cugraph_graph_create_sg_from_csr(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* offsets,
+  const cugraph_type_erased_device_array_view_t* indices,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+cugraph_error_code_t cugraph_sg_graph_create_from_csr(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* offsets,
+  const cugraph_type_erased_device_array_view_t* indices,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
+  bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+
+void cugraph_graph_free(cugraph_graph_t* graph);    /* graph.h:321 */
+void cugraph_sg_graph_free(cugraph_graph_t* graph); /* graph.h:330 */
+
+/* ---- cpp/include/cugraph_c/centrality_algorithms.h:35-83, 122-307 ---- */
+typedef struct { int32_t align_; } cugraph_centrality_result_t;
+
+/* each getter returns a NEW heap view the caller frees (cpp/src/c_api/centrality_result.cpp:21-35) */
+cugraph_type_erased_device_array_view_t* cugraph_centrality_result_get_vertices(
+  cugraph_centrality_result_t* result);
+cugraph_type_erased_device_array_view_t* cugraph_centrality_result_get_values(
+  cugraph_centrality_result_t* result);
+size_t cugraph_centrality_result_get_num_iterations(cugraph_centrality_result_t* result);
+bool_t cugraph_centrality_result_converged(cugraph_centrality_result_t* result);
+void cugraph_centrality_result_free(cugraph_centrality_result_t* result);
+
+/* centrality_algorithms.h:122 (impl cpp/src/c_api/pagerank.cpp:254-321): returns
+ * CUGRAPH_UNKNOWN_ERROR "PageRank failed to converge." when not converged, with *result
+ * still populated.  epsilon is compared with the L1 delta as is (pagerank_impl.cuh:330). */
+cugraph_error_code_t cugraph_pagerank(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error);
+
+/* centrality_algorithms.h:177 (impl pagerank.cpp:323-383) */
+cugraph_error_code_t cugraph_pagerank_allow_nonconvergence(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error);
+
+/* centrality_algorithms.h:236 (impl pagerank.cpp:385-471) */
+cugraph_error_code_t cugraph_personalized_pagerank(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values,
+  const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error);
+
+/* centrality_algorithms.h:293 (impl pagerank.cpp:473-552) */
+cugraph_error_code_t cugraph_personalized_pagerank_allow_nonconvergence(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values,
+  const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+  double epsilon, size_t max_iterations, bool_t do_expensive_check,
+  cugraph_centrality_result_t** result, cugraph_error_t** error);
+
+/* ===================================================================== */
+/* Part 2 -- extensions (no counterpart in the reference)                 */
+/* ===================================================================== */
+
+/* Handle bound to an existing HIP stream (hipStream_t passed as void*, NULL = the NULL stream)
+ * and, for the 1D multi-GPU partition, this process's rank / world size (replaces the raft
+ * comms handle the reference gets from Dask, python/cugraph/cugraph/dask/comms/comms.py:89-158). */
+cugraph_resource_handle_t* cugraph_amd_create_resource_handle(void* hip_stream, int rank,
+                                                              int comm_size);
+
+/* Local part of a 1D destination-partitioned graph: this rank owns destinations
+ * [vertex_first, vertex_last) of num_global_vertices and must be given exactly the edges whose
+ * dst lies in that range (any src).  Always stored transposed (CSC, global source ids). */
+cugraph_error_code_t cugraph_amd_graph_create_local(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights, int64_t vertex_first,
+  int64_t vertex_last, int64_t num_global_vertices, cugraph_graph_t** graph,
+  cugraph_error_t** error);
+
+/* Shape of a graph: info[0]=num_vertices (local majors), [1]=num_edges, [2]=num_global_vertices,
+ * [3]=vertex_first, [4]=store_transposed, [5]=offsets are int64, [6]=weighted, [7]=renumbered */
+cugraph_error_code_t cugraph_amd_graph_info(const cugraph_graph_t* graph, int64_t info[8],
+                                            cugraph_error_t** error);
+
+/* Read-only views of the compressed arrays the graph holds (new heap views, caller frees each;
+ * weights view is NULL for an unweighted graph, number_map view NULL when ids are 0..V-1).
+ * For parity tests of the COO->CSC build. */
+cugraph_error_code_t cugraph_amd_graph_get_compressed(
+  cugraph_graph_t* graph, cugraph_type_erased_device_array_view_t** offsets,
+  cugraph_type_erased_device_array_view_t** indices,
+  cugraph_type_erased_device_array_view_t** weights,
+  cugraph_type_erased_device_array_view_t** number_map, cugraph_error_t** error);
+
+/* Sum over this graph's edges of the weight (1 if unweighted) per SOURCE vertex, written to
+ * `sums` (FLOAT64, num_global_vertices elements).  The multi-GPU driver all-reduces these and
+ * hands each rank its slice as precomputed_vertex_out_weight_sums. */
+cugraph_error_code_t cugraph_amd_graph_source_weight_sums(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  cugraph_type_erased_device_array_view_t* sums, cugraph_error_t** error);
+
+/* R-MAT edges [first_edge, first_edge + n) of the stream (seed, a, b, c) into INT32 views src/dst
+ * of n elements (quadrant rule of cpp/src/generators/generate_rmat_edgelist.cu:85-102; own
+ * Philox4x32-10 stream so that the CPU oracle emits the identical list). */
+cugraph_error_code_t cugraph_amd_generate_rmat_edgelist(
+  const cugraph_resource_handle_t* handle, size_t scale, uint64_t first_edge, uint64_t seed,
+  double a, double b, double c, bool_t scramble_vertex_ids,
+  cugraph_type_erased_device_array_view_t* src, cugraph_type_erased_device_array_view_t* dst,
+  cugraph_error_t** error);
+
+/* Weights in (0,1] for edges [first_edge, first_edge + n), FLOAT32 or FLOAT64 view. */
+cugraph_error_code_t cugraph_amd_generate_rmat_weights(
+  const cugraph_resource_handle_t* handle, uint64_t first_edge, uint64_t seed,
+  cugraph_type_erased_device_array_view_t* weights, cugraph_error_t** error);
+
+/* ---- step-wise PageRank session ----
+ * Same arguments as cugraph_personalized_pagerank_allow_nonconvergence (personalization may be
+ * NULL).  create() allocates the rank / source-value buffers and computes out-weight sums;
+ * iterate() enqueues up to n iterations on the handle's stream WITHOUT synchronising: once
+ * the L1 delta of the previous iteration is below epsilon the remaining enqueued iterations
+ * are no-ops on the device.  status() synchronises.  cugraph_pagerank* are thin loops over this. */
+typedef struct { int32_t align_; } cugraph_amd_pagerank_session_t;
+
+cugraph_error_code_t cugraph_amd_pagerank_session_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values,
+  const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+  double epsilon, bool_t do_expensive_check, cugraph_amd_pagerank_session_t** session,
+  cugraph_error_t** error);
+
+/* Enqueue n iterations (each: SpMV with fused epilogue + scalar finalize). */
+cugraph_error_code_t cugraph_amd_pagerank_session_iterate(cugraph_amd_pagerank_session_t* session,
+                                                          size_t n, cugraph_error_t** error);
+
+/* As iterate(), but brackets every iteration and its SpMV launch with HIP events on the handle's
+ * stream, synchronises, and returns the n per-iteration and per-SpMV-kernel durations in
+ * milliseconds (either output may be NULL).  For bench.py's roofline figure. */
+cugraph_error_code_t cugraph_amd_pagerank_session_timed_iterate(
+  cugraph_amd_pagerank_session_t* session, size_t n, float* iteration_ms, float* spmv_kernel_ms,
+  cugraph_error_t** error);
+
+/* Multi-GPU hooks.  After each iterate(1) the driver must (a) all-gather the source-value
+ * vector and (b) all-reduce the two scalars, both in place on the handle's stream order:
+ *   *x_full  : FLOAT32/64 view of num_global_vertices elements, the vector the NEXT iteration
+ *              gathers from; this rank has just written [vertex_first, vertex_last) of it;
+ *   *scalars : FLOAT64 view of 2 elements {dangling mass, L1 delta} (local sums).
+ * Caller frees both views. */
+cugraph_error_code_t cugraph_amd_pagerank_session_exchange_buffers(
+  cugraph_amd_pagerank_session_t* session, cugraph_type_erased_device_array_view_t** x_full,
+  cugraph_type_erased_device_array_view_t** scalars, cugraph_error_t** error);
+
+/* Synchronise and report: iterations executed, whether the stop criterion has fired, the last
+ * L1 delta and dangling mass. */
+cugraph_error_code_t cugraph_amd_pagerank_session_status(cugraph_amd_pagerank_session_t* session,
+                                                         size_t* num_iterations,
+                                                         bool_t* stopped, double* l1_delta,
+                                                         double* dangling_mass,
+                                                         cugraph_error_t** error);
+
+/* Copy the current ranks out as a centrality result (vertex ids + values); `max_iterations`
+ * only decides the converged flag (converged <=> stopped with iterations < max_iterations,
+ * pagerank_impl.cuh:337). */
+cugraph_error_code_t cugraph_amd_pagerank_session_result(cugraph_amd_pagerank_session_t* session,
+                                                         size_t max_iterations,
+                                                         cugraph_centrality_result_t** result,
+                                                         cugraph_error_t** error);
+
+/* info[0]=algorithmic bytes per iteration, [1]=edges per iteration,
+ * [2]=low-degree vertices, [3]=mid-degree vertices, [4]=hub vertices, [5]=zero in-degree vertices,
+ * [6]=workgroups of the SpMV launch, [7]=reserved */
+cugraph_error_code_t cugraph_amd_pagerank_session_info(cugraph_amd_pagerank_session_t* session,
+                                                       int64_t info[8], cugraph_error_t** error);
+
+void cugraph_amd_pagerank_session_free(cugraph_amd_pagerank_session_t* session);
+
+const char* cugraph_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUGRAPH_AMD_C_H */

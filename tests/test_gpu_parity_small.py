@@ -1,0 +1,172 @@
+"""GPU parity, small cases: golden vectors of the reference's own tests + oracle comparisons,
+all through the C ABI (pylibcugraph mirror).  Bit-exact for the CSC, reference tolerances for
+the floating-point ranks."""
+import numpy as np
+import pytest
+
+from helpers import case_arrays, compressed_arrays, load_csv, make_sg_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect_close(actual, expected, rel):
+    actual = np.asarray(actual, dtype=np.float64)
+    expected = np.asarray(expected, dtype=np.float64)
+    assert actual.shape == expected.shape
+    assert np.all(np.abs(actual - expected) <= rel * np.maximum(np.abs(actual), np.abs(expected)))
+
+
+@pytest.mark.parametrize("name", ["karate.csv", "dolphins.csv", "Simple_1", "Simple_2"])
+def test_pylibcugraph_goldens(golden, name):
+    # python/pylibcugraph/pylibcugraph/tests/test_pagerank.py:175-218
+    from cugraph_amd import pylibcugraph as plc
+    import torch
+
+    block = golden["pylibcugraph"]
+    case = block["cases"][name]
+    src, dst, wgt = case_arrays(case)
+    g, h = make_sg_graph(src, dst, wgt, store_transposed=True)
+    verts, ranks = plc.pagerank(h, g, None, None, None, None, block["alpha"], block["epsilon"],
+                                block["max_iterations"], False)
+    assert verts.dtype == torch.int32 and ranks.dtype == torch.float32
+    verts = verts.cpu().numpy()
+    ranks = ranks.cpu().numpy()
+    expected = np.array(case["expected"])
+    assert sorted(verts.tolist()) == list(range(len(expected)))
+    _expect_close(ranks, expected[verts], block["rel_tol"])
+
+
+@pytest.mark.parametrize("name", [
+    "test_pagerank", "test_pagerank_with_transpose", "test_pagerank_4",
+    "test_pagerank_4_with_transpose", "test_pagerank_non_convergence",
+    "test_personalized_pagerank", "test_personalized_pagerank_non_convergence"])
+def test_c_api_goldens(golden, name):
+    # cpp/tests/c_api/pagerank_test.c:396-555
+    from cugraph_amd import pylibcugraph as plc
+
+    block = golden["c_api"]
+    case = block["cases"][name]
+    src, dst, wgt = case_arrays(case)
+    g, h = make_sg_graph(src, dst, wgt, store_transposed=case["store_transposed"])
+    allow = case["allow_nonconvergence"]
+    if "pers_vertices" in case:
+        out = plc.personalized_pagerank(
+            h, g, None, None, None, None, to_dev(np.array(case["pers_vertices"], np.int32)),
+            to_dev(np.array(case["pers_values"], np.float32)), case["alpha"], case["epsilon"],
+            case["max_iterations"], False, fail_on_nonconvergence=not allow)
+    else:
+        out = plc.pagerank(h, g, None, None, None, None, case["alpha"], case["epsilon"],
+                           case["max_iterations"], False, fail_on_nonconvergence=not allow)
+    verts, ranks = out[0].cpu().numpy(), out[1].cpu().numpy()
+    if allow:
+        assert out[2] is False  # both non-convergence cases stop at max_iterations
+    _expect_close(ranks, np.array(case["expected"])[verts], block["rel_tol"])
+    assert g.info()["store_transposed"] == 1  # transposed in place if it was not (pagerank.cpp:105-110)
+
+
+def test_nonconvergence_raises(golden):
+    # python/cugraph/cugraph/tests/link_analysis/test_pagerank.py:427-469
+    from cugraph_amd import pylibcugraph as plc
+
+    src, dst, wgt = load_csv("karate.csv")
+    g, h = make_sg_graph(src, dst, wgt)
+    with pytest.raises(plc.FailedToConvergeError):
+        plc.pagerank(h, g, None, None, None, None, 0.85, 1e-12, 1, False)
+    v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-12, 1, False,
+                              fail_on_nonconvergence=False)
+    assert conv is False and len(r) == 34
+
+
+@pytest.mark.parametrize("name", ["karate.csv", "dolphins.csv", "netscience.csv", "polbooks.csv",
+                                  "karate_multi_edge.csv", "karate_s_loop.csv"])
+@pytest.mark.parametrize("transposed", [True, False])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_compressed_layout_bit_exact(name, transposed, weighted):
+    """COO -> CSC/CSR equals the (major, minor)-lexicographic definition, bit for bit."""
+    import oracle
+
+    src, dst, wgt = load_csv(name)
+    if weighted:  # make weights distinct so that a wrong permutation cannot hide
+        wgt = (np.arange(len(src)) * 0.37 + 1.0).astype(np.float32)
+    nv = int(max(src.max(), dst.max())) + 1
+    g, h = make_sg_graph(src, dst, wgt if weighted else None, store_transposed=transposed,
+                         multigraph=True)
+    off, idx, w, nm = compressed_arrays(g, h)
+    major, minor = (dst, src) if transposed else (src, dst)
+    o_off, o_idx, o_w = oracle.csc_lexsort(nv, minor, major, wgt if weighted else None)
+    assert np.array_equal(off.astype(np.int64), o_off)
+    assert np.array_equal(idx, o_idx)
+    if weighted:
+        assert np.array_equal(w, o_w)
+    else:
+        assert w is None
+    assert nm is None
+
+
+@pytest.mark.parametrize("scale,ef", [(8, 4), (12, 16), (16, 16)])
+@pytest.mark.parametrize("scramble", [False, True])
+def test_rmat_generator_matches_oracle(scale, ef, scramble):
+    import ctypes
+    import torch
+    import oracle
+    from cugraph_amd import _capi, pylibcugraph as plc
+    from cugraph_amd.pylibcugraph.utils import create_view_from_py_obj, free_view
+
+    lib = _capi.load()
+    h = plc.ResourceHandle()
+    ne = ef << scale
+    src = torch.empty(ne, dtype=torch.int32, device="cuda")
+    dst = torch.empty(ne, dtype=torch.int32, device="cuda")
+    sv, dv = create_view_from_py_obj(src), create_view_from_py_obj(dst)
+    err = ctypes.c_void_p()
+    code = lib.cugraph_amd_generate_rmat_edgelist(h.c_resource_handle_ptr, scale, 0, 42, 0.57, 0.19,
+                                                  0.19, int(scramble), sv, dv, ctypes.byref(err))
+    _capi.check(code, err, "rmat")
+    free_view(sv), free_view(dv)
+    o_src, o_dst = oracle.rmat_edges(scale, ne, seed=42, scramble=scramble)
+    assert np.array_equal(src.cpu().numpy(), o_src)
+    assert np.array_equal(dst.cpu().numpy(), o_dst)
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        w = torch.empty(1000, dtype=tdt, device="cuda")
+        wv = create_view_from_py_obj(w)
+        code = lib.cugraph_amd_generate_rmat_weights(h.c_resource_handle_ptr, 5, 43, wv,
+                                                     ctypes.byref(err))
+        _capi.check(code, err, "rmat_weights")
+        free_view(wv)
+        assert np.array_equal(w.cpu().numpy(), oracle.rmat_weights(1000, seed=43, first=5).astype(dt))
+
+
+@pytest.mark.parametrize("scale", [10, 14, 17])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_rmat_pagerank_vs_oracle(scale, dtype, weighted):
+    """R-MAT (hubs, multi-edges, self-loops, dangling and isolated vertices): CSC bit-exact, ranks
+    within 1e-6 (fp32) / 1e-10 (fp64) max-abs of the C oracle, same iteration count."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=42)
+    wgt = oracle.rmat_weights(ne, seed=43).astype(dtype) if weighted else None
+    verts = np.arange(nv, dtype=np.int32)
+    g, h = make_sg_graph(src, dst, wgt, vertices=verts, multigraph=True)
+    off, idx, w, _ = compressed_arrays(g, h)
+    o_off, o_idx, perm = oracle.compress(nv, dst, src)
+    assert np.array_equal(off.astype(np.int64), o_off)
+    assert np.array_equal(idx, o_idx)
+    if weighted:
+        assert np.array_equal(w, wgt[perm])
+    elif dtype == np.float64:
+        pytest.skip("an unweighted graph always computes in fp32 (graph_sg.cpp:247)")
+    eps = nv * 1e-8  # NetworkX tol=1e-8 through nx-cugraph's epsilon = N*tol (pagerank_alg.py:81)
+    v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, eps, 500, False,
+                              fail_on_nonconvergence=False)
+    o_pr, o_it, o_conv = oracle.pagerank(nv, o_off, o_idx, None if wgt is None else wgt[perm],
+                                         dtype=np.float64, alpha=0.85, epsilon=eps,
+                                         max_iterations=500)
+    assert conv and o_conv
+    r = r.cpu().numpy().astype(np.float64)
+    assert np.array_equal(v.cpu().numpy(), verts)
+    tol = 1e-6 if dtype == np.float32 else 1e-10
+    assert np.max(np.abs(r - o_pr)) <= tol
+    assert abs(r.sum() - 1.0) < (1e-4 if dtype == np.float32 else 1e-10)
