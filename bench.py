@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- PageRank iteration throughput on synthetic R-MAT (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W            (one process)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE PageRank iteration over the whole graph (pull SpMV with the fused rank update,
+source-value update, dangling-mass and L1-delta partial sums, plus the scalar finalize; for N>1
+also the all-gather of the source vector and the 2-scalar all-reduce).  The workload is the
+configuration the metric is quoted on: R-MAT scale 26, edge factor 16 (67M vertices / 1.07B
+edges), unweighted fp32, inputs resident in HBM before the timed region; with N ranks the SAME
+graph is 1D-partitioned by destination (strong scaling).  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--scale", type=int, default=26)
+    p.add_argument("--edge-factor", type=int, default=16)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--scramble", type=int, default=1, help="scramble R-MAT vertex ids (0/1)")
+    p.add_argument("--cpu-scale", type=int, default=21, help="R-MAT scale of the CPU-baseline sample")
+    p.add_argument("--renumber", type=int, default=1,
+                   help="build the graph with renumber=True, cugraph.Graph's default (0/1)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-convergence", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """The C oracle (a port of the reference's CPU pagerank_reference) on a bounded sample of the
+    same workload -- same generator, parameters and edge factor at a smaller scale -- timed on this
+    box's host cores.  Reported, not a target."""
+    import numpy as np
+
+    import oracle
+
+    scale = args.cpu_scale
+    nv, ne = 1 << scale, args.edge_factor << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=args.seed, scramble=bool(args.scramble))
+    off, idx, _ = oracle.compress(nv, dst, src)
+    iters = 8
+    t0 = time.perf_counter()
+    oracle.pagerank(nv, off, idx, None, dtype=np.float32, alpha=0.85, epsilon=0.0,
+                    max_iterations=iters)
+    dt = time.perf_counter() - t0
+    return {
+        "value": ne * iters / dt / 1e9,
+        "unit": "GTEPS",
+        "cores": oracle.num_threads(),
+        "kind": "port",
+        "sample": f"R-MAT scale {scale} ef {args.edge_factor} ({ne} edges), {iters} iterations of the "
+                  f"OpenMP C oracle, {dt:.2f} s incl. out-degree pass; CSC build not timed",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+
+    from cugraph_amd import generators, pylibcugraph as plc
+    from cugraph_amd.session import PagerankSession
+
+    scale, ef = args.scale, args.edge_factor
+    nv, ne = 1 << scale, ef << scale
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    handle = plc.ResourceHandle(rank=rank, comm_size=world) if world > 1 else plc.ResourceHandle()
+    props = plc.GraphProperties(is_symmetric=False, is_multigraph=True)
+
+    # ---------------- inputs (untimed): R-MAT edges generated on the device, then the CSC build
+    t_build0 = time.perf_counter()
+    if world == 1:
+        src, dst = generators.rmat(handle, scale, ne, seed=args.seed,
+                                   scramble_vertex_ids=bool(args.scramble))
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t_build0
+        t0 = time.perf_counter()
+        graph = plc.SGGraph(handle, props, src, dst, store_transposed=True,
+                            renumber=bool(args.renumber),
+                            vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+        torch.cuda.synchronize()
+        t_csc = time.perf_counter() - t0
+        del src, dst
+        torch.cuda.empty_cache()
+        mg = None
+    else:
+        from cugraph_amd import mg as mgmod
+
+        mg = mgmod.MGPagerank.from_rmat(handle, props, scale, ne, seed=args.seed,
+                                        scramble_vertex_ids=bool(args.scramble))
+        torch.cuda.synchronize()
+        t_gen, t_csc = mg.t_generate, mg.t_build
+        graph = mg.graph
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- timed region: K iterations, epsilon = 0 so that none is skipped
+    if world == 1:
+        sess = PagerankSession(handle, graph, alpha=0.85, epsilon=0.0)
+        step = lambda n: sess.iterate(n)  # noqa: E731
+    else:
+        sess = mg.session(alpha=0.85, epsilon=0.0)
+        step = lambda n: mg.iterate(sess, n)  # noqa: E731
+    step(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    gteps = ne / (elapsed / args.steps) / 1e9
+
+    # ---------------- dominant kernel, live HIP events on the launch stream (rank-local)
+    inner = sess if world == 1 else sess.inner
+    info = inner.info()
+    n_probe = min(args.steps, 10)
+    iter_ms, kern_ms = inner.timed_iterate(n_probe) if world == 1 else mg.timed_iterate(sess, n_probe)
+    kern_avg_ms = float(kern_ms.mean())
+    bytes_per_launch = info["bytes_per_iteration"]  # this rank's share for N > 1
+    achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm",
+        "kernel": "spmv_kernel",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "kernel_ms_avg": kern_avg_ms,
+        "iteration_ms_event_avg": float(iter_ms.mean()),
+    }
+
+    # ---------------- time to convergence at NetworkX tol = 1e-8 (epsilon = N * tol)
+    conv = None
+    if not args.no_convergence:
+        del sess
+        eps = nv * 1e-8
+        barrier()
+        t0 = time.perf_counter()
+        if world == 1:
+            s2 = PagerankSession(handle, graph, alpha=0.85, epsilon=eps)
+            it, stopped = 0, False
+            while not stopped and it < 500:
+                s2.iterate(4)
+                it, stopped, delta, _ = s2.status()
+        else:
+            s2 = mg.session(alpha=0.85, epsilon=eps)
+            it, stopped, delta = mg.run_to_convergence(s2, 500)
+        barrier()
+        conv = {"iterations": it, "converged": bool(stopped), "seconds": time.perf_counter() - t0,
+                "l1_delta": delta, "epsilon": eps}
+        del s2
+
+    out = {
+        "metric": "PageRank GTEPS/iter + achieved HBM GB/s, R-MAT scale 26 at 1/2/4/8 MI355X",
+        "value": gteps,
+        "unit": "GTEPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"R-MAT scale {scale} ef {ef} (a=.57 b=.19 c=.19, seed {args.seed}, "
+                        f"{'scrambled' if args.scramble else 'natural'} ids), {nv} vertices / {ne} edges, "
+                        "unweighted fp32 PageRank alpha=0.85, one iteration per step",
+            "partition": "single GPU" if world == 1 else f"1D by destination over {world} GPUs",
+            "renumber": bool(args.renumber) if world == 1 else False,
+        },
+        "achieved_hbm_GBps_whole_iteration": info["bytes_per_iteration"] * (world if world > 1 else 1)
+        / (ms_per_step * 1e-3) / 1e9,
+        "roofline": roofline,
+        "graph_build": {"generate_s": t_gen, "coo_to_csc_s": t_csc,
+                        "edges_per_s": ne / t_csc if t_csc > 0 else None},
+        "time_to_convergence": conv,
+        "buckets": {k: info[k] for k in ("low_degree_vertices", "mid_degree_vertices", "hub_vertices",
+                                         "spmv_workgroups")},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,17 +87,17 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
               "vertex ids must be INT32 or INT64");
   CGA_EXPECTS(!weights || is_float_type(weights->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
               "edge weights must be FLOAT32 or FLOAT64");
-  CGA_EXPECTS(!renumber, CUGRAPH_NOT_IMPLEMENTED,
-              "renumber=TRUE is not implemented yet: pass contiguous ids 0..V-1 with renumber=FALSE");
   CGA_EXPECTS(!drop_self_loops && !drop_multi_edges, CUGRAPH_NOT_IMPLEMENTED,
               "drop_self_loops / drop_multi_edges are not implemented");
 
   hipStream_t stream = h.stream;
   int64_t ne         = static_cast<int64_t>(src->size);
   DevBuf s32(static_cast<size_t>(ne > 0 ? ne : 1) * 4), d32(static_cast<size_t>(ne > 0 ? ne : 1) * 4);
-  int64_t smin = 0, dmin = 0;
-  int64_t smax = narrow_ids(stream, src->data, src->type, src->size, s32.as<int32_t>(), &smin);
-  int64_t dmax = narrow_ids(stream, dst->data, dst->type, dst->size, d32.as<int32_t>(), &dmin);
+  int64_t smin = 0, dmin = 0, smax = -1, dmax = -1;
+  if (!renumber) {
+    smax = narrow_ids(stream, src->data, src->type, src->size, s32.as<int32_t>(), &smin);
+    dmax = narrow_ids(stream, dst->data, dst->type, dst->size, d32.as<int32_t>(), &dmin);
+  }
 
   auto g              = std::make_unique<Graph>();
   g->vertex_type      = src->type;
@@ -124,6 +124,11 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
     n_major                = g->num_vertices;
     n_minor                = num_global;
     major_shift            = vertex_first;
+  } else if (renumber) {
+    // create_graph_from_edgelist_impl.cuh:925-941: ids become 0..V-1 by descending major degree
+    renumber_edgelist(h, *g, vertices, src, dst, store_transposed, s32.as<int32_t>(),
+                      d32.as<int32_t>());
+    n_major = n_minor = g->num_vertices;
   } else {
     // create_graph_from_edgelist_impl.cuh:939-949
     int64_t nv = vertices ? static_cast<int64_t>(vertices->size)

@@ -7,6 +7,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -150,6 +151,7 @@ struct Graph {
   bool is_symmetric{false};
   bool is_multigraph{false};
   bool renumbered{false};
+  bool degree_sorted{false};  // majors are in descending-degree order (contiguous degree buckets)
 
   int64_t num_vertices{0};         // majors held here (SG: all vertices)
   int64_t num_global_vertices{0};  // id space of the minors (== num_vertices on one GPU)
@@ -161,6 +163,11 @@ struct Graph {
   int32_t* indices{nullptr};  // [num_edges]
   void* weights{nullptr};     // float/double [num_edges] or nullptr
   void* number_map{nullptr};  // internal id -> external id, vertex_type[num_vertices]; nullptr = identity
+  // external id -> internal id: ext_lookup[id - ext_min], -1 where the id is not a vertex
+  // (set together with number_map: renumber=TRUE graphs and degree-sorted plan copies)
+  int32_t* ext_lookup{nullptr};
+  int64_t ext_min{0};
+  int64_t ext_range{0};
 
   PullPlan* plan{nullptr};  // cached by the first PageRank call on this graph
 
@@ -210,6 +217,13 @@ void fill_sequence(hipStream_t stream, void* out, cugraph_data_type_id_t type, s
                    int64_t first);
 
 void transpose_graph(Handle const& h, Graph& g);
+
+// renumber.hip
+void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf& order, DevBuf& rank);
+void relabel_ids(hipStream_t stream, int32_t* ids, int64_t n, int32_t const* table);
+Graph* degree_sorted_copy(Handle const& h, Graph const& g);
+void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
+                       ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32);
 
 // out[i] = in[i] - shift  /  out[i] = (int64) in[i]
 void shift_ids(hipStream_t stream, int32_t const* in, int32_t* out, int64_t n, int64_t shift);

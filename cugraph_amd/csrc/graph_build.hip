@@ -592,6 +592,7 @@ void transpose_graph(Handle const& h, Graph& g)
   g.indices = static_cast<int32_t*>(out.indices.detach());
   g.weights = out.weights.p ? out.weights.detach() : nullptr;
   g.store_transposed = !g.store_transposed;
+  g.degree_sorted    = false;  // the order was by the OTHER endpoint's degree
   if (g.plan) {
     destroy_plan(g.plan);
     g.plan = nullptr;
@@ -604,6 +605,7 @@ Graph::~Graph()
   if (indices) (void)hipFree(indices);
   if (weights) (void)hipFree(weights);
   if (number_map) (void)hipFree(number_map);
+  if (ext_lookup) (void)hipFree(ext_lookup);
   if (plan) destroy_plan(plan);
 }
 

@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -332,16 +333,39 @@ __global__ void source_sums_kernel(int32_t const* __restrict__ indices,
     atomicAdd(&sums[indices[e]], weights ? static_cast<double>(weights[e]) : 1.0);
 }
 
-// (vertex, value) pairs -> dense local vector; ids outside the local range are counted, not stored
+// external id -> row of the compute graph, through up to two lookup tables
+struct IdMap {
+  int32_t const* lookup0;  // graph's own renumber map (external -> graph id), or nullptr
+  int64_t min0, range0;
+  int32_t const* lookup1;  // plan's degree-sort permutation (graph id -> plan row), or nullptr
+  int64_t first;           // first global id of the local range (no lookup0)
+  int64_t count;           // rows
+  __device__ inline int64_t row(int64_t id) const
+  {
+    int64_t v;
+    if (lookup0) {
+      int64_t k = id - min0;
+      if (k < 0 || k >= range0) return -1;
+      v = lookup0[k];
+      if (v < 0) return -1;
+    } else {
+      v = id - first;
+      if (v < 0 || v >= count) return -1;
+    }
+    return lookup1 ? static_cast<int64_t>(lookup1[v]) : v;
+  }
+};
+
+// (vertex, value) pairs -> dense vector over the compute graph's rows; unknown ids are counted
 template <typename IdT, typename ValT, bool ACCUMULATE>
 __global__ void scatter_pairs_kernel(IdT const* __restrict__ ids, ValT const* __restrict__ vals,
-                                     int64_t n, int64_t first, int64_t count,
-                                     ValT* __restrict__ dense, unsigned int* __restrict__ n_bad)
+                                     int64_t n, IdMap map, ValT* __restrict__ dense,
+                                     unsigned int* __restrict__ n_bad)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t v = static_cast<int64_t>(ids[i]) - first;
-    if (v < 0 || v >= count) {
+    int64_t v = map.row(static_cast<int64_t>(ids[i]));
+    if (v < 0) {
       atomicAdd(n_bad, 1u);
     } else if constexpr (ACCUMULATE) {
       atomicAdd(&dense[v], vals[i]);
@@ -349,6 +373,15 @@ __global__ void scatter_pairs_kernel(IdT const* __restrict__ ids, ValT const* __
       dense[v] = vals[i];
     }
   }
+}
+
+template <typename ValT>
+__global__ void permute_out_kernel(ValT const* __restrict__ in, int32_t const* __restrict__ order,
+                                   int64_t n, ValT* __restrict__ out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[order[i]] = in[i];
 }
 
 template <typename ValT>
@@ -433,11 +466,14 @@ void exclusive_scan_u32_to_i64(hipStream_t stream, unsigned int const* counts, i
 // ------------------------------------------------------------------ plan (cached on the graph)
 // Degree buckets as ascending index lists over the graph's own vertex order.
 struct PullPlan {
+  Graph* internal{nullptr};  // degree-sorted copy the kernels run on (nullptr: the graph itself)
   DevBuf lists[kNumBuckets];
   int64_t counts[kNumBuckets]{};
-  int64_t n_zero_degree{0};
-  DevBuf out_w_sums;  // double[num_global_vertices]: per-source weight sums of THIS graph's edges
+  int64_t firsts[kNumBuckets]{};
+  bool contiguous{false};  // buckets are row ranges, no index lists
+  DevBuf out_w_sums;  // double[num_global_vertices]: per-source weight sums, compute-graph order
   bool have_out_w{false};
+  ~PullPlan() { delete internal; }
 };
 
 void destroy_plan(PullPlan* p) { delete p; }
@@ -452,6 +488,8 @@ template <typename OffT>
 void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
 {
   int64_t n = g.num_vertices;
+  plan.contiguous = g.degree_sorted;
+  int64_t running = 0;
   DevBuf flags(static_cast<size_t>(n > 0 ? n : 1) * sizeof(unsigned int));
   DevBuf pos(static_cast<size_t>(n + 1) * sizeof(int64_t));
   for (int b = 0; b < kNumBuckets; ++b) {
@@ -466,7 +504,9 @@ void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
                            stream));
     CGA_HIP(hipStreamSynchronize(stream));
     plan.counts[b] = total;
-    if (total > 0 && total < n) {
+    plan.firsts[b] = plan.contiguous ? running : 0;
+    running += total;
+    if (!plan.contiguous && total > 0 && total < n) {
       plan.lists[b].alloc(static_cast<size_t>(total) * sizeof(int32_t));
       hipLaunchKernelGGL(compact_ids_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, n,
                          flags.as<unsigned int>(), pos.as<int64_t>(), plan.lists[b].as<int32_t>());
@@ -476,15 +516,23 @@ void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipStreamSynchronize(stream));
 }
 
-PullPlan& get_plan(hipStream_t stream, Graph& g)
+PullPlan& get_plan(Handle const& h, Graph& g)
 {
+  hipStream_t stream = h.stream;
   if (!g.plan) {
     auto* p = new PullPlan();
     try {
-      if (g.off64)
-        build_plan_lists<int64_t>(stream, g, *p);
+      // graphs that are not already in descending in-degree order get a degree-sorted copy to
+      // run on (single GPU; CUGRAPH_AMD_NO_RELABEL=1 keeps the index-list buckets instead)
+      char const* no_relabel = std::getenv("CUGRAPH_AMD_NO_RELABEL");
+      bool relabel = !(no_relabel && no_relabel[0] == '1') && !g.degree_sorted &&
+                     g.num_global_vertices == g.num_vertices && g.num_vertices > 0;
+      if (relabel) p->internal = degree_sorted_copy(h, g);
+      Graph const& cg = p->internal ? *p->internal : g;
+      if (cg.off64)
+        build_plan_lists<int64_t>(stream, cg, *p);
       else
-        build_plan_lists<int32_t>(stream, g, *p);
+        build_plan_lists<int32_t>(stream, cg, *p);
     } catch (...) {
       delete p;
       throw;
@@ -516,7 +564,9 @@ void compute_source_sums(hipStream_t stream, Graph const& g, double* sums)
 // ------------------------------------------------------------------ session
 struct Session {
   Handle const* handle{nullptr};
-  Graph* graph{nullptr};
+  Graph* graph{nullptr};        // the caller's graph
+  Graph const* cg{nullptr};     // the graph the kernels run on (graph, or its degree-sorted copy)
+  int32_t const* order{nullptr};  // cg row -> graph row when cg is a copy
   bool f64{false};
   double alpha{0.85}, epsilon{0.0};
   int64_t n_local{0}, n_global{0};
@@ -538,7 +588,7 @@ namespace {
 
 template <typename ValT>
 void dense_from_pairs(hipStream_t stream, ArrayView const* ids, ArrayView const* vals,
-                      int64_t first, int64_t count, ValT* dense, bool accumulate, char const* what)
+                      IdMap const& map, ValT* dense, bool accumulate, char const* what)
 {
   CGA_EXPECTS(ids && vals, CUGRAPH_INVALID_INPUT,
               std::string(what) + ": vertices and values must both be given");
@@ -553,12 +603,12 @@ void dense_from_pairs(hipStream_t stream, ArrayView const* ids, ArrayView const*
     if (accumulate)
       hipLaunchKernelGGL((scatter_pairs_kernel<IdT, ValT, true>), dim3(grid_for(n)), dim3(kThreads),
                          0, stream, static_cast<IdT const*>(ids->data),
-                         static_cast<ValT const*>(vals->data), n, first, count, dense,
+                         static_cast<ValT const*>(vals->data), n, map, dense,
                          bad.as<unsigned int>());
     else
       hipLaunchKernelGGL((scatter_pairs_kernel<IdT, ValT, false>), dim3(grid_for(n)),
                          dim3(kThreads), 0, stream, static_cast<IdT const*>(ids->data),
-                         static_cast<ValT const*>(vals->data), n, first, count, dense,
+                         static_cast<ValT const*>(vals->data), n, map, dense,
                          bad.as<unsigned int>());
   };
   if (ids->type == INT32)
@@ -576,10 +626,20 @@ void dense_from_pairs(hipStream_t stream, ArrayView const* ids, ArrayView const*
 template <typename ValT>
 void session_setup(Session& s, PagerankArgs const& a)
 {
-  Graph& g           = *s.graph;
   hipStream_t stream = s.handle->stream;
+  PullPlan& plan     = get_plan(*s.handle, *s.graph);
+  s.cg               = plan.internal ? plan.internal : s.graph;
+  s.order            = plan.internal ? static_cast<int32_t const*>(plan.internal->number_map) : nullptr;
+  Graph const& g     = *s.cg;
   int64_t nl = s.n_local, ng = s.n_global;
   size_t vb = sizeof(ValT);
+  IdMap idmap{};
+  idmap.lookup0 = s.graph->ext_lookup;
+  idmap.min0    = s.graph->ext_min;
+  idmap.range0  = s.graph->ext_range;
+  idmap.lookup1 = plan.internal ? plan.internal->ext_lookup : nullptr;
+  idmap.first   = s.graph->vertex_first;
+  idmap.count   = nl;
 
   for (int k = 0; k < 2; ++k) {
     s.pr[k].alloc(static_cast<size_t>(nl > 0 ? nl : 1) * vb);
@@ -593,13 +653,11 @@ void session_setup(Session& s, PagerankArgs const& a)
   CGA_HIP(hipMemsetAsync(s.x[0].p, 0, s.x[0].bytes, stream));
   CGA_HIP(hipMemsetAsync(s.x[1].p, 0, s.x[1].bytes, stream));
 
-  PullPlan& plan = get_plan(stream, g);
-
   // ---- out-weight sums: given (pagerank.cpp:158-184) or computed once per graph and cached
   if (a.pre_sums) {
     CGA_HIP(hipMemsetAsync(s.out_w.p, 0, s.out_w.bytes, stream));
-    dense_from_pairs<ValT>(stream, a.pre_vertices, a.pre_sums, g.vertex_first, nl,
-                           s.out_w.as<ValT>(), false, "precomputed_vertex_out_weight");
+    dense_from_pairs<ValT>(stream, a.pre_vertices, a.pre_sums, idmap, s.out_w.as<ValT>(), false,
+                           "precomputed_vertex_out_weight");
     if (a.do_expensive_check && nl > 0) {
       DevBuf chk(sizeof(double) + sizeof(unsigned int) * 2);
       CGA_HIP(hipMemsetAsync(chk.p, 0, chk.bytes, stream));
@@ -630,8 +688,8 @@ void session_setup(Session& s, PagerankArgs const& a)
   //      (pagerank_impl.cuh:430-440; pagerank.cpp:186-212)
   if (a.guess_values) {
     CGA_HIP(hipMemsetAsync(s.pr[0].p, 0, s.pr[0].bytes, stream));
-    dense_from_pairs<ValT>(stream, a.guess_vertices, a.guess_values, g.vertex_first, nl,
-                           s.pr[0].as<ValT>(), false, "initial_guess");
+    dense_from_pairs<ValT>(stream, a.guess_vertices, a.guess_values, idmap, s.pr[0].as<ValT>(),
+                           false, "initial_guess");
   } else if (nl > 0) {
     hipLaunchKernelGGL((fill_kernel<ValT>), dim3(grid_for(nl)), dim3(kThreads), 0, stream,
                        s.pr[0].as<ValT>(), nl, ValT(1) / static_cast<ValT>(ng));
@@ -658,7 +716,7 @@ void session_setup(Session& s, PagerankArgs const& a)
       hipLaunchKernelGGL((value_checks_kernel<ValT>), dim3(grid_for(np, 1024)), dim3(kThreads), 0,
                          stream, static_cast<ValT const*>(a.pers_values->data), np,
                          chk.as<double>(), reinterpret_cast<unsigned int*>(chk.as<double>() + 1));
-      dense_from_pairs<ValT>(stream, a.pers_vertices, a.pers_values, g.vertex_first, nl,
+      dense_from_pairs<ValT>(stream, a.pers_vertices, a.pers_values, idmap,
                              s.pers_dense.as<ValT>(), true, "personalization");
     }
     struct {
@@ -709,13 +767,16 @@ void session_setup(Session& s, PagerankArgs const& a)
 
   // ---- launch geometry: all buckets in one grid, hubs first
   int begin = 0;
+  // timing aid: CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets (results are then wrong)
+  char const* mask_env = std::getenv("CUGRAPH_AMD_BUCKET_MASK");
+  int bucket_mask      = mask_env ? std::atoi(mask_env) : 0xF;
   int const group_width[kNumBuckets] = {kThreads, 64, 16, 1};
   int const block_cap[kNumBuckets]   = {1024, 2048, 2048, 2048};
   for (int b = 0; b < kNumBuckets; ++b) {
     Bucket& bk    = s.buckets[b];
-    bk.count      = plan.counts[b];
+    bk.count      = ((bucket_mask >> b) & 1) ? plan.counts[b] : 0;
     bk.list       = plan.lists[b].p ? plan.lists[b].as<int32_t>() : nullptr;
-    bk.first      = 0;
+    bk.first      = plan.firsts[b];
     int64_t need  = (bk.count * group_width[b] + kThreads - 1) / kThreads;
     bk.n_blocks   = static_cast<int>(std::min<int64_t>(need, block_cap[b]));
     bk.block_begin = begin;
@@ -742,7 +803,7 @@ void session_setup(Session& s, PagerankArgs const& a)
 template <typename OffT, typename ValT>
 void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end)
 {
-  Graph& g           = *s.graph;
+  Graph const& g     = *s.cg;
   hipStream_t stream = s.handle->stream;
   int cur = static_cast<int>(s.enqueued & 1), nxt = cur ^ 1;
   IterArgs<OffT, ValT> a{};
@@ -788,7 +849,7 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
 
 void enqueue_dispatch(Session& s, hipEvent_t b, hipEvent_t e)
 {
-  bool o64 = s.graph->off64;
+  bool o64 = s.cg->off64;
   if (s.f64) {
     if (o64) enqueue_iteration<int64_t, double>(s, b, e);
     else enqueue_iteration<int32_t, double>(s, b, e);
@@ -897,8 +958,21 @@ CentralityResult* session_result(Session& s, size_t max_iterations)
     if (s.n_local > 0) {
       CGA_HIP(hipMalloc(&vals->data, vals->nbytes));
       CGA_HIP(hipMalloc(&ids->data, ids->nbytes));
-      CGA_HIP(hipMemcpyAsync(vals->data, s.pr[iters & 1].p, vals->nbytes, hipMemcpyDeviceToDevice,
-                             stream));
+      if (s.order) {  // ranks were computed on the degree-sorted copy: back to the graph's order
+        int grid = grid_for(s.n_local);
+        if (s.f64)
+          hipLaunchKernelGGL((permute_out_kernel<double>), dim3(grid), dim3(kThreads), 0, stream,
+                             s.pr[iters & 1].as<double>(), s.order, s.n_local,
+                             static_cast<double*>(vals->data));
+        else
+          hipLaunchKernelGGL((permute_out_kernel<float>), dim3(grid), dim3(kThreads), 0, stream,
+                             s.pr[iters & 1].as<float>(), s.order, s.n_local,
+                             static_cast<float*>(vals->data));
+        CGA_HIP(hipGetLastError());
+      } else {
+        CGA_HIP(hipMemcpyAsync(vals->data, s.pr[iters & 1].p, vals->nbytes, hipMemcpyDeviceToDevice,
+                               stream));
+      }
       if (g.number_map)
         CGA_HIP(hipMemcpyAsync(ids->data, g.number_map, ids->nbytes, hipMemcpyDeviceToDevice, stream));
       else
@@ -919,7 +993,7 @@ CentralityResult* session_result(Session& s, size_t max_iterations)
 
 void session_info(Session& s, int64_t info[8])
 {
-  Graph& g     = *s.graph;
+  Graph const& g = *s.cg;
   int64_t bval = s.f64 ? 8 : 4;
   int64_t bw   = g.weights ? bval : 0;
   int64_t boff = g.off64 ? 8 : 4;

@@ -1,0 +1,371 @@
+// Vertex renumbering: external ids -> dense internal ids ordered by DESCENDING major degree
+// (in-degree for the transposed / pull layout), ties by ascending external id.
+//
+// Replaces compute_renumber_map / renumber_edgelist (reference:
+// cpp/src/structure/renumber_edgelist_impl.cuh:238-607, 1056-1104).  The reference gets its unique
+// vertex set from E-sized sorts + merges, its degrees from sort + reduce_by_key, orders by
+// sort_by_key(greater) and relabels through a cuco hash map.  Here:
+//   - the vertex set comes from a direct-address flag table over [min id, max id] + one scan
+//     (ids must span less than 2^31; hashed ids wider than that are NOT_IMPLEMENTED);
+//   - degrees come from the same histogram kernel as the CSC build;
+//   - the order is a stable LSD radix split, one bit per pass (flag + scan + scatter), so the
+//     result is deterministic;
+//   - relabelling is a table lookup.
+// Degree-descending order is what gives the SpMV contiguous degree buckets (the reference's
+// segment_offsets, renumber_edgelist_impl.cuh:546-603) and packs the hot sources of a
+// power-law graph into a few MB of the gathered vector.
+#include "common.hpp"
+
+namespace cga {
+
+void exclusive_scan_u32_to_i64(hipStream_t stream, unsigned int const* counts, int64_t n,
+                               int64_t* out);
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int grid_for(int64_t items, int cap = 256 * 16)
+{
+  int64_t b = (items + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return static_cast<int>(b);
+}
+
+#define GRID_STRIDE(i, n)                                                        \
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n);      \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void max_u32_kernel(unsigned int const* v, int64_t n, unsigned int* out)
+{
+  unsigned int m = 0;
+  GRID_STRIDE(i, n) m = v[i] > m ? v[i] : m;
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned int t = __shfl_xor(m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__global__ void iota_kernel(int32_t* v, int64_t n) { GRID_STRIDE(i, n) v[i] = (int32_t)i; }
+
+__global__ void bit_flag_kernel(unsigned int const* keys, int64_t n, int bit, unsigned int* flags)
+{
+  GRID_STRIDE(i, n) flags[i] = (keys[i] >> bit) & 1u;
+}
+
+// stable split, ones first (descending order)
+__global__ void bit_split_kernel(unsigned int const* keys_in, int32_t const* vals_in, int64_t n,
+                                 int bit, int64_t const* ones_before, unsigned int* keys_out,
+                                 int32_t* vals_out)
+{
+  int64_t total_ones = ones_before[n];
+  GRID_STRIDE(i, n)
+  {
+    unsigned int k = keys_in[i];
+    int64_t ob     = ones_before[i];
+    int64_t pos    = ((k >> bit) & 1u) ? ob : total_ones + (i - ob);
+    keys_out[pos]  = k;
+    vals_out[pos]  = vals_in[i];
+  }
+}
+
+__global__ void invert_kernel(int32_t const* order, int64_t n, int32_t* rank)
+{
+  GRID_STRIDE(i, n) rank[order[i]] = (int32_t)i;
+}
+
+__global__ void relabel_kernel(int32_t* ids, int64_t n, int32_t const* table)
+{
+  GRID_STRIDE(i, n) ids[i] = table[ids[i]];
+}
+
+template <typename OffT>
+__global__ void degree_from_offsets_kernel(OffT const* offsets, int64_t n, unsigned int* deg)
+{
+  GRID_STRIDE(i, n) deg[i] = (unsigned int)(offsets[i + 1] - offsets[i]);
+}
+
+__global__ void hist_u32_kernel(int32_t const* keys, int64_t n, unsigned int* counts)
+{
+  GRID_STRIDE(i, n) atomicAdd(&counts[keys[i]], 1u);
+}
+
+// ---- arbitrary external ids -> dense ids (ascending id order)
+template <typename IdT>
+__global__ void mark_ids_kernel(IdT const* ids, int64_t n, long long lo, unsigned int* flags)
+{
+  GRID_STRIDE(i, n) flags[(long long)ids[i] - lo] = 1u;
+}
+
+template <typename IdT>
+__global__ void to_dense_kernel(IdT const* ids, int64_t n, long long lo, unsigned int const* flags,
+                                int64_t const* pos, int32_t* out, unsigned int* n_unknown)
+{
+  GRID_STRIDE(i, n)
+  {
+    long long k = (long long)ids[i] - lo;
+    if (!flags[k]) atomicAdd(n_unknown, 1u);
+    out[i] = (int32_t)pos[k];
+  }
+}
+
+template <typename IdT>
+__global__ void number_map_kernel(int64_t range, long long lo, unsigned int const* flags,
+                                  int64_t const* pos, int32_t const* rank, IdT* number_map,
+                                  int32_t* lookup)
+{
+  GRID_STRIDE(k, range)
+  {
+    if (flags[k]) {
+      int32_t nw     = rank[pos[k]];
+      number_map[nw] = (IdT)(lo + k);
+      lookup[k]      = nw;
+    } else {
+      lookup[k] = -1;
+    }
+  }
+}
+
+template <typename IdT>
+__global__ void minmax_kernel(IdT const* in, int64_t n, long long* minmax)
+{
+  long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+  GRID_STRIDE(i, n)
+  {
+    long long v = (long long)in[i];
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(minmax, lo);
+    atomicMax(minmax + 1, hi);
+  }
+}
+
+inline int bit_width_u32(unsigned int v)
+{
+  int b = 0;
+  while (v) { ++b; v >>= 1; }
+  return b;
+}
+
+}  // namespace
+
+// order[new] = old, rank[old] = new; stable, descending degree
+void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf& order, DevBuf& rank)
+{
+  size_t nn = static_cast<size_t>(n > 0 ? n : 1);
+  order.alloc(nn * sizeof(int32_t));
+  rank.alloc(nn * sizeof(int32_t));
+  if (n == 0) return;
+  DevBuf keys_a(nn * 4), keys_b(nn * 4), vals_b(nn * 4), flags(nn * 4), pos((nn + 1) * 8), mx(4);
+  CGA_HIP(hipMemcpyAsync(keys_a.p, deg, nn * 4, hipMemcpyDeviceToDevice, stream));
+  CGA_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+  hipLaunchKernelGGL(max_u32_kernel, dim3(grid_for(n, 1024)), dim3(kThreads), 0, stream, deg, n,
+                     mx.as<unsigned int>());
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, order.as<int32_t>(), n);
+  unsigned int h_max = 0;
+  CGA_HIP(hipMemcpyAsync(&h_max, mx.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  unsigned int* kin  = keys_a.as<unsigned int>();
+  unsigned int* kout = keys_b.as<unsigned int>();
+  int32_t* vin       = order.as<int32_t>();
+  int32_t* vout      = vals_b.as<int32_t>();
+  int bits           = bit_width_u32(h_max);
+  for (int b = 0; b < bits; ++b) {
+    hipLaunchKernelGGL(bit_flag_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, kin, n, b,
+                       flags.as<unsigned int>());
+    exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n, pos.as<int64_t>());
+    hipLaunchKernelGGL(bit_split_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, kin, vin, n,
+                       b, pos.as<int64_t>(), kout, vout);
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  if (vin != order.as<int32_t>())
+    CGA_HIP(hipMemcpyAsync(order.p, vin, nn * 4, hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(invert_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                     order.as<int32_t>(), n, rank.as<int32_t>());
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
+}
+
+void relabel_ids(hipStream_t stream, int32_t* ids, int64_t n, int32_t const* table)
+{
+  if (n == 0) return;
+  hipLaunchKernelGGL(relabel_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, ids, n, table);
+  CGA_HIP(hipGetLastError());
+}
+
+// A degree-sorted copy of a compressed graph whose ids are 0..V-1 (the pull plan of graphs built
+// with renumber=FALSE).  number_map (int32) and ext_lookup describe the permutation.
+Graph* degree_sorted_copy(Handle const& h, Graph const& g)
+{
+  hipStream_t stream = h.stream;
+  int64_t n = g.num_vertices, ne = g.num_edges;
+  CGA_EXPECTS(g.num_global_vertices == g.num_vertices, CUGRAPH_NOT_IMPLEMENTED,
+              "degree-sorted copies of partitioned graphs are not supported");
+  DevBuf deg(static_cast<size_t>(n > 0 ? n : 1) * 4);
+  if (n > 0) {
+    if (g.off64)
+      hipLaunchKernelGGL((degree_from_offsets_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0,
+                         stream, static_cast<int64_t const*>(g.offsets), n, deg.as<unsigned int>());
+    else
+      hipLaunchKernelGGL((degree_from_offsets_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0,
+                         stream, static_cast<int32_t const*>(g.offsets), n, deg.as<unsigned int>());
+  }
+  DevBuf order, rank;
+  degree_order(stream, deg.as<unsigned int>(), n, order, rank);
+  deg.release();
+  DevBuf majors(static_cast<size_t>(ne > 0 ? ne : 1) * 4), minors(static_cast<size_t>(ne > 0 ? ne : 1) * 4);
+  expand_offsets(stream, g.offsets, g.off64, n, ne, majors.as<int32_t>());
+  if (ne > 0)
+    CGA_HIP(hipMemcpyAsync(minors.p, g.indices, static_cast<size_t>(ne) * 4, hipMemcpyDeviceToDevice, stream));
+  relabel_ids(stream, majors.as<int32_t>(), ne, rank.as<int32_t>());
+  relabel_ids(stream, minors.as<int32_t>(), ne, rank.as<int32_t>());
+  CompressedOut out = compress_coo(stream, n, n, ne, majors.as<int32_t>(), minors.as<int32_t>(),
+                                   g.weights, g.weights ? dtype_size(g.weight_type) : 0);
+  auto ig                 = std::make_unique<Graph>();
+  ig->vertex_type         = INT32;
+  ig->edge_type           = g.edge_type;
+  ig->weight_type         = g.weight_type;
+  ig->store_transposed    = g.store_transposed;
+  ig->is_symmetric        = g.is_symmetric;
+  ig->is_multigraph       = g.is_multigraph;
+  ig->renumbered          = true;
+  ig->degree_sorted       = true;
+  ig->num_vertices        = n;
+  ig->num_global_vertices = n;
+  ig->num_edges           = ne;
+  ig->off64               = out.off64;
+  ig->offsets             = out.offsets.detach();
+  ig->indices             = static_cast<int32_t*>(out.indices.detach());
+  ig->weights             = out.weights.p ? out.weights.detach() : nullptr;
+  ig->number_map          = order.detach();
+  ig->ext_lookup          = static_cast<int32_t*>(rank.detach());
+  ig->ext_min             = 0;
+  ig->ext_range           = n;
+  return ig.release();
+}
+
+// renumber=TRUE: arbitrary external ids (vertex_type) -> degree-sorted dense ids.
+// On return src32/dst32 hold the relabelled endpoints, g.number_map / ext_lookup are set and
+// g.num_vertices is the number of distinct vertices.
+void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
+                       ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32)
+{
+  hipStream_t stream = h.stream;
+  int64_t ne         = static_cast<int64_t>(src->size);
+  bool wide          = src->type == INT64;
+  // ---- id range
+  DevBuf mm(2 * sizeof(long long));
+  long long init[2] = {0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1};
+  CGA_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  auto scan_minmax = [&](ArrayView const* a) {
+    if (!a || a->size == 0) return;
+    int64_t n = static_cast<int64_t>(a->size);
+    if (wide)
+      hipLaunchKernelGGL((minmax_kernel<int64_t>), dim3(grid_for(n, 1024)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(a->data), n, mm.as<long long>());
+    else
+      hipLaunchKernelGGL((minmax_kernel<int32_t>), dim3(grid_for(n, 1024)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(a->data), n, mm.as<long long>());
+  };
+  scan_minmax(vertices);
+  scan_minmax(src);
+  scan_minmax(dst);
+  long long h_mm[2];
+  CGA_HIP(hipMemcpyAsync(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  bool empty = h_mm[1] < h_mm[0];
+  long long lo = empty ? 0 : h_mm[0];
+  long long range = empty ? 0 : h_mm[1] - h_mm[0] + 1;
+  CGA_EXPECTS(range < 0x7fffffffLL, CUGRAPH_NOT_IMPLEMENTED,
+              "renumber=TRUE: vertex ids must span less than 2^31 (max id - min id)");
+  size_t rr = static_cast<size_t>(range > 0 ? range : 1);
+  // ---- vertex set: the given list, or every endpoint
+  DevBuf flags(rr * 4), pos((rr + 1) * 8);
+  CGA_HIP(hipMemsetAsync(flags.p, 0, rr * 4, stream));
+  auto mark = [&](ArrayView const* a) {
+    if (!a || a->size == 0) return;
+    int64_t n = static_cast<int64_t>(a->size);
+    if (wide)
+      hipLaunchKernelGGL((mark_ids_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(a->data), n, lo, flags.as<unsigned int>());
+    else
+      hipLaunchKernelGGL((mark_ids_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(a->data), n, lo, flags.as<unsigned int>());
+  };
+  if (vertices) {
+    mark(vertices);
+  } else {
+    mark(src);
+    mark(dst);
+  }
+  exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), range, pos.as<int64_t>());
+  int64_t nv = 0;
+  CGA_HIP(hipMemcpyAsync(&nv, pos.as<int64_t>() + range, 8, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  // ---- endpoints -> dense (ascending-id) labels
+  DevBuf unknown(4);
+  CGA_HIP(hipMemsetAsync(unknown.p, 0, 4, stream));
+  auto densify = [&](ArrayView const* a, int32_t* out) {
+    if (a->size == 0) return;
+    int64_t n = static_cast<int64_t>(a->size);
+    if (wide)
+      hipLaunchKernelGGL((to_dense_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(a->data), n, lo, flags.as<unsigned int>(),
+                         pos.as<int64_t>(), out, unknown.as<unsigned int>());
+    else
+      hipLaunchKernelGGL((to_dense_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(a->data), n, lo, flags.as<unsigned int>(),
+                         pos.as<int64_t>(), out, unknown.as<unsigned int>());
+  };
+  densify(src, src32);
+  densify(dst, dst32);
+  unsigned int h_unknown = 0;
+  CGA_HIP(hipMemcpyAsync(&h_unknown, unknown.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  CGA_EXPECTS(h_unknown == 0, CUGRAPH_INVALID_INPUT,
+              "Invalid input arguments: edge endpoints missing from the vertex list.");
+  // ---- major degrees, order, relabel
+  DevBuf deg(static_cast<size_t>(nv > 0 ? nv : 1) * 4);
+  CGA_HIP(hipMemsetAsync(deg.p, 0, deg.bytes, stream));
+  if (ne > 0)
+    hipLaunchKernelGGL(hist_u32_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                       majors_are_dst ? dst32 : src32, ne, deg.as<unsigned int>());
+  DevBuf order, rank;
+  degree_order(stream, deg.as<unsigned int>(), nv, order, rank);
+  relabel_ids(stream, src32, ne, rank.as<int32_t>());
+  relabel_ids(stream, dst32, ne, rank.as<int32_t>());
+  // ---- number_map (new -> external) and the external -> new lookup
+  DevBuf nmap(static_cast<size_t>(nv > 0 ? nv : 1) * dtype_size(g.vertex_type));
+  DevBuf lookup(rr * 4);
+  if (range > 0) {
+    if (wide)
+      hipLaunchKernelGGL((number_map_kernel<int64_t>), dim3(grid_for(range)), dim3(kThreads), 0, stream,
+                         range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
+                         nmap.as<int64_t>(), lookup.as<int32_t>());
+    else
+      hipLaunchKernelGGL((number_map_kernel<int32_t>), dim3(grid_for(range)), dim3(kThreads), 0, stream,
+                         range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
+                         nmap.as<int32_t>(), lookup.as<int32_t>());
+  }
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
+  g.num_vertices = g.num_global_vertices = nv;
+  g.renumbered   = true;
+  g.degree_sorted = true;
+  g.number_map   = nmap.detach();
+  g.ext_lookup   = static_cast<int32_t*>(lookup.detach());
+  g.ext_min      = lo;
+  g.ext_range    = range;
+}
+
+}  // namespace cga

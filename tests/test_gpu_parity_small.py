@@ -170,3 +170,96 @@ def test_rmat_pagerank_vs_oracle(scale, dtype, weighted):
     tol = 1e-6 if dtype == np.float32 else 1e-10
     assert np.max(np.abs(r - o_pr)) <= tol
     assert abs(r.sum() - 1.0) < (1e-4 if dtype == np.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("name", ["karate.csv", "dolphins.csv", "netscience.csv"])
+@pytest.mark.parametrize("id_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("transposed", [True, False])
+def test_renumber_true_external_ids(name, id_dtype, transposed):
+    """renumber=TRUE (cugraph.Graph's default, simpleGraph.py:1134): arbitrary, non-contiguous,
+    negative external ids; result vertices are the external ids; ranks equal the oracle's on the
+    relabelled graph; the graph itself is stored in descending in-degree order."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    src, dst, wgt = load_csv(name)
+    nv = int(max(src.max(), dst.max())) + 1
+    ext = (np.arange(nv, dtype=np.int64) * 7 - 50).astype(id_dtype)  # gaps and negative ids
+    g, h = make_sg_graph(ext[src], ext[dst], wgt, store_transposed=transposed, renumber=True,
+                         vertices=ext)  # the vertex list keeps ids that no edge mentions
+    info = g.info()
+    assert info["renumbered"] == 1 and info["num_vertices"] == nv
+    off, idx, w, nmap = compressed_arrays(g, h)
+    assert nmap.dtype == id_dtype and sorted(nmap.tolist()) == sorted(ext.tolist())
+    deg = np.diff(off)
+    assert np.all(deg[:-1] >= deg[1:])  # descending major degree
+    # ties by ascending external id (stable)
+    same = deg[:-1] == deg[1:]
+    assert np.all(nmap[:-1][same] < nmap[1:][same])
+    # stored structure == oracle CSC of the relabelled edge list
+    inv = {int(e): i for i, e in enumerate(nmap)}
+    s2 = np.array([inv[int(e)] for e in ext[src]], np.int32)
+    d2 = np.array([inv[int(e)] for e in ext[dst]], np.int32)
+    major, minor = (d2, s2) if transposed else (s2, d2)
+    o_off, o_idx, o_w = oracle.csc_lexsort(nv, minor, major, wgt)
+    assert np.array_equal(off.astype(np.int64), o_off) and np.array_equal(idx, o_idx)
+    assert np.array_equal(w, o_w)
+    # PageRank with a personalization and an initial guess given in EXTERNAL ids
+    pv = ext[np.array([3, 1, 7])]
+    pvals = np.array([0.2, 0.5, 0.3], np.float32)
+    gv = ext[np.arange(nv)]
+    gvals = np.full(nv, 1.0 / nv, np.float32)
+    v, r = plc.personalized_pagerank(h, g, None, None, to_dev(gv), to_dev(gvals), to_dev(pv),
+                                     to_dev(pvals), 0.85, 1e-7, 500, False)
+    c_off, c_idx, perm = oracle.compress(nv, dst, src)
+    o_pr, _, _ = oracle.pagerank(nv, c_off, c_idx, wgt[perm], dtype=np.float64, alpha=0.85,
+                                 epsilon=1e-7, max_iterations=500, nstart=gvals.astype(np.float64),
+                                 pers_vertices=np.array([3, 1, 7]), pers_values=pvals)
+    v = v.cpu().numpy()
+    assert v.dtype == id_dtype and np.array_equal(v, nmap)
+    got = np.empty(nv)
+    got[[int((e + 50) // 7) for e in v]] = r.cpu().numpy()
+    assert np.max(np.abs(got - o_pr)) <= 2e-6
+
+
+def test_unknown_vertex_ids_rejected():
+    from cugraph_amd import pylibcugraph as plc
+
+    src, dst, wgt = load_csv("karate.csv")
+    g, h = make_sg_graph(src, dst, wgt)
+    with pytest.raises(ValueError):
+        plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.array([99], np.int32)),
+                                  to_dev(np.array([1.0], np.float32)), 0.85, 1e-6, 100, False)
+    with pytest.raises(ValueError):  # dtype of the values must match the graph's weights
+        plc.pagerank(h, g, None, None, to_dev(np.arange(34, dtype=np.int32)),
+                     to_dev(np.full(34, 1 / 34, np.float64)), 0.85, 1e-6, 100, False)
+
+
+@pytest.mark.parametrize("relabel", ["0", "1"])
+def test_nstart_and_precomputed_out_weights(relabel, monkeypatch):
+    """nstart is used verbatim (pagerank_impl.cuh:435-439), missing vertices start at 0
+    (pagerank.cpp:202-211); precomputed out-weight sums replace the computed ones."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_NO_RELABEL", relabel)
+    src, dst, wgt = load_csv("dolphins.csv")
+    nv = 62
+    g, h = make_sg_graph(src, dst, wgt)
+    rng = np.random.default_rng(3)
+    gv = rng.permutation(nv)[:40].astype(np.int32)
+    gvals = rng.random(40).astype(np.float32)
+    nstart = np.zeros(nv)
+    nstart[gv] = gvals
+    c_off, c_idx, perm = oracle.compress(nv, dst, src)
+    out_w = np.bincount(src, weights=wgt.astype(np.float64), minlength=nv)
+    fake_w = (out_w * 2.0).astype(np.float32)  # any consistent scaling must pass through
+    v, r, conv = plc.pagerank(h, g, to_dev(np.arange(nv, dtype=np.int32)), to_dev(fake_w),
+                              to_dev(gv), to_dev(gvals), 0.85, 1e-7, 3, False,
+                              fail_on_nonconvergence=False)
+    o_pr, o_it, o_conv = oracle.pagerank(nv, c_off, c_idx, wgt[perm], dtype=np.float64, alpha=0.85,
+                                         epsilon=1e-7, max_iterations=3, nstart=nstart,
+                                         out_weight_sums=fake_w.astype(np.float64))
+    assert conv == o_conv
+    assert np.array_equal(v.cpu().numpy(), np.arange(nv))
+    assert np.max(np.abs(r.cpu().numpy() - o_pr)) <= 1e-6
