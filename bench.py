@@ -35,6 +35,8 @@ def parse():
     p.add_argument("--cpu-scale", type=int, default=21, help="R-MAT scale of the CPU-baseline sample")
     p.add_argument("--renumber", type=int, default=1,
                    help="build the graph with renumber=True, cugraph.Graph's default (0/1)")
+    p.add_argument("--force-mg", action="store_true",
+                   help="run the multi-GPU driver (and its collectives) even with one rank")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-convergence", action="store_true")
     return p.parse_args()
@@ -85,17 +87,22 @@ def main():
     nv, ne = 1 << scale, ef << scale
 
     dist = None
-    if world > 1:
+    use_mg = world > 1 or args.force_mg
+    if use_mg:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
-    handle = plc.ResourceHandle(rank=rank, comm_size=world) if world > 1 else plc.ResourceHandle()
+    handle = plc.ResourceHandle(rank=rank, comm_size=world) if use_mg else plc.ResourceHandle()
     props = plc.GraphProperties(is_symmetric=False, is_multigraph=True)
 
     # ---------------- inputs (untimed): R-MAT edges generated on the device, then the CSC build
     t_build0 = time.perf_counter()
-    if world == 1:
+    if not use_mg:
         src, dst = generators.rmat(handle, scale, ne, seed=args.seed,
                                    scramble_vertex_ids=bool(args.scramble))
         torch.cuda.synchronize()
@@ -114,6 +121,7 @@ def main():
 
         mg = mgmod.MGPagerank.from_rmat(handle, props, scale, ne, seed=args.seed,
                                         scramble_vertex_ids=bool(args.scramble))
+        mg.always_exchange = True
         torch.cuda.synchronize()
         t_gen, t_csc = mg.t_generate, mg.t_build
         graph = mg.graph
@@ -124,7 +132,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------- timed region: K iterations, epsilon = 0 so that none is skipped
-    if world == 1:
+    if not use_mg:
         sess = PagerankSession(handle, graph, alpha=0.85, epsilon=0.0)
         step = lambda n: sess.iterate(n)  # noqa: E731
     else:
@@ -144,10 +152,10 @@ def main():
     gteps = ne / (elapsed / args.steps) / 1e9
 
     # ---------------- dominant kernel, live HIP events on the launch stream (rank-local)
-    inner = sess if world == 1 else sess.inner
+    inner = sess if not use_mg else sess.inner
     info = inner.info()
     n_probe = min(args.steps, 10)
-    iter_ms, kern_ms = inner.timed_iterate(n_probe) if world == 1 else mg.timed_iterate(sess, n_probe)
+    iter_ms, kern_ms = inner.timed_iterate(n_probe) if not use_mg else mg.timed_iterate(sess, n_probe)
     kern_avg_ms = float(kern_ms.mean())
     bytes_per_launch = info["bytes_per_iteration"]  # this rank's share for N > 1
     achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
@@ -171,7 +179,7 @@ def main():
         eps = nv * 1e-8
         barrier()
         t0 = time.perf_counter()
-        if world == 1:
+        if not use_mg:
             s2 = PagerankSession(handle, graph, alpha=0.85, epsilon=eps)
             it, stopped = 0, False
             while not stopped and it < 500:
@@ -202,8 +210,8 @@ def main():
             "workload": f"R-MAT scale {scale} ef {ef} (a=.57 b=.19 c=.19, seed {args.seed}, "
                         f"{'scrambled' if args.scramble else 'natural'} ids), {nv} vertices / {ne} edges, "
                         "unweighted fp32 PageRank alpha=0.85, one iteration per step",
-            "partition": "single GPU" if world == 1 else f"1D by destination over {world} GPUs",
-            "renumber": bool(args.renumber) if world == 1 else False,
+            "partition": "single GPU" if not use_mg else f"1D by destination over {world} GPUs",
+            "renumber": bool(args.renumber) if not use_mg else False,
         },
         "achieved_hbm_GBps_whole_iteration": info["bytes_per_iteration"] * (world if world > 1 else 1)
         / (ms_per_step * 1e-3) / 1e9,

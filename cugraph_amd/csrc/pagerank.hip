@@ -570,6 +570,7 @@ struct Session {
   bool f64{false};
   double alpha{0.85}, epsilon{0.0};
   int64_t n_local{0}, n_global{0};
+  int64_t x_len{0};  // length of the gathered vector: n_global, padded to comm_size equal chunks
   DevBuf pr[2], x[2], out_w, pers_dense, pers_v, pers_p, partials, scal, ctrl;
   int64_t n_pers{0};       // entries of the compact list (sparse mode)
   bool personalized{false};
@@ -641,9 +642,22 @@ void session_setup(Session& s, PagerankArgs const& a)
   idmap.first   = s.graph->vertex_first;
   idmap.count   = nl;
 
+  // 1D partition: rank r owns destinations [r*chunk, min((r+1)*chunk, V)), chunk = ceil(V / P);
+  // the gathered vector is padded to P equal chunks so that one all-gather fills it
+  s.x_len = ng;
+  if (g.num_global_vertices != g.num_vertices || s.handle->comm_size > 1) {
+    int64_t P     = s.handle->comm_size;
+    int64_t chunk = (ng + P - 1) / P;
+    int64_t first = std::min<int64_t>(chunk * s.handle->rank, ng);
+    int64_t last  = std::min<int64_t>(first + chunk, ng);
+    CGA_EXPECTS(g.vertex_first == first && g.num_vertices == last - first, CUGRAPH_INVALID_INPUT,
+                "partitioned graph: this rank must own destinations [rank*ceil(V/P), ...) "
+                "(see cugraph_amd.mg.partition_bounds)");
+    s.x_len = chunk * P;
+  }
   for (int k = 0; k < 2; ++k) {
     s.pr[k].alloc(static_cast<size_t>(nl > 0 ? nl : 1) * vb);
-    s.x[k].alloc(static_cast<size_t>(ng > 0 ? ng : 1) * vb);
+    s.x[k].alloc(static_cast<size_t>(s.x_len > 0 ? s.x_len : 1) * vb);
   }
   s.out_w.alloc(static_cast<size_t>(nl > 0 ? nl : 1) * vb);
   s.scal.alloc(2 * sizeof(double));
@@ -1015,7 +1029,7 @@ void session_exchange_buffers(Session& s, void** x_full, void** scalars)
 
 void session_destroy(Session* s) { delete s; }
 bool session_is_f64(Session& s) { return s.f64; }
-int64_t session_num_global(Session& s) { return s.n_global; }
+int64_t session_num_global(Session& s) { return s.x_len; }
 
 CentralityResult* run_pagerank(Handle const& h, Graph& g, PagerankArgs const& a)
 {

@@ -1,0 +1,298 @@
+"""Multi-GPU PageRank: 1D destination-vertex partition over the GPUs of one node.
+
+One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Replaces, for this path, the reference's Dask layer
+(python/cugraph/cugraph/dask/link_analysis/pagerank.py:174-440), its 2D edge partitioning
+(cpp/include/cugraph/partition_manager.hpp:32-145) and the raft-comms collectives listed in
+SURVEY.md section 2.3:
+
+  build      : edges are routed to the owner of their DESTINATION with one all-to-all
+               (reference: shuffle over the 2D grid + per-block renumbering);
+               out-weight sums are per SOURCE, so one all-reduce of a V-length vector gives every
+               rank the sums of its own vertices (reference: device_reduce over major_comm,
+               per_v_transform_reduce_incoming_outgoing_e.cuh:1094-1108);
+  iteration  : local pull SpMV with the fused epilogue (same kernels as one GPU; a 1D
+               destination partition has no partial sums, so the reference's reduce over
+               minor_comm, :955-1013, disappears), then
+               ONE all-gather of the source-value vector x (reference: grouped device_bcast,
+               update_edge_src_dst_property.cuh:559-588) and
+               ONE all-reduce of {dangling mass, L1 delta} (reference: two blocking
+               host_scalar_allreduce, reduce_v.cuh:141-144);
+  stop       : decided on the device from the all-reduced delta, identically on every rank.
+
+Rank r owns destinations [r*chunk, min((r+1)*chunk, V)) with chunk = ceil(V / P).
+
+The local compute is reached through an *engine* object so that the driver logic (partition,
+routing, collectives, stop rule, result assembly) can be exercised at world_size 2 on CPU with
+a test double; the product engine is `HipEngine` and there is no other in this package.
+"""
+import time
+
+import numpy as np
+
+
+def partition_bounds(num_vertices, world_size, rank):
+    """[first, last) of the destinations rank owns; chunk = ceil(V / P)."""
+    chunk = (num_vertices + world_size - 1) // world_size
+    first = min(rank * chunk, num_vertices)
+    last = min(first + chunk, num_vertices)
+    return first, last, chunk
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def all_gather_in_place(x_full, chunk, rank, world, group=None):
+    """x_full[r*chunk:(r+1)*chunk] of every rank -> x_full of every rank."""
+    dist = _dist()
+    mine = x_full[rank * chunk:(rank + 1) * chunk]
+    try:
+        dist.all_gather_into_tensor(x_full, mine, group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the flat form (gloo)
+        parts = list(x_full.split(chunk))
+        dist.all_gather(parts, mine.clone(), group=group)
+
+
+def shuffle_edges_to_owner(src, dst, wgt, chunk, world, group=None):
+    """Route every edge to the rank that owns its destination (one all-to-all per array)."""
+    import torch
+
+    dist = _dist()
+    owner = torch.div(dst, chunk, rounding_mode="floor").to(torch.int64)
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=world)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    in_split = [int(c) for c in send_counts.tolist()]
+    out_split = [int(c) for c in recv_counts.tolist()]
+
+    def route(a):
+        a = a[order].contiguous()
+        out = torch.empty(sum(out_split), dtype=a.dtype, device=a.device)
+        dist.all_to_all_single(out, a, output_split_sizes=out_split, input_split_sizes=in_split,
+                               group=group)
+        return out
+
+    return route(src), route(dst), (None if wgt is None else route(wgt))
+
+
+class HipEngine:
+    """Local compute on one MI355X through the C ABI."""
+
+    def __init__(self, resource_handle, graph_properties):
+        self.handle = resource_handle
+        self.props = graph_properties
+        self.device = "cuda"
+
+    def make_local_graph(self, src, dst, wgt, first, last, num_global):
+        from . import pylibcugraph as plc
+
+        return plc.MGGraph(self.handle, self.props, src, dst, wgt, vertex_first=first,
+                           vertex_last=last, num_global_vertices=num_global)
+
+    def source_weight_sums(self, graph, num_global):
+        import ctypes
+
+        import torch
+
+        from . import _capi
+        from .pylibcugraph.utils import create_view_from_py_obj, free_view
+
+        sums = torch.zeros(num_global, dtype=torch.float64, device="cuda")
+        view = create_view_from_py_obj(sums)
+        err = ctypes.c_void_p()
+        try:
+            code = _capi.load().cugraph_amd_graph_source_weight_sums(
+                self.handle.c_resource_handle_ptr, graph.c_graph_ptr, view, ctypes.byref(err))
+            _capi.check(code, err, "cugraph_amd_graph_source_weight_sums")
+        finally:
+            free_view(view)
+        return sums
+
+    def make_session(self, graph, **kw):
+        from .session import PagerankSession
+
+        return PagerankSession(self.handle, graph, **kw)
+
+
+class MGSession:
+    def __init__(self, inner):
+        self.inner = inner
+
+
+class MGPagerank:
+    """Driver of a 1D-partitioned PageRank.  Construct with from_edges / from_rmat."""
+
+    def __init__(self, engine, num_vertices, rank, world, group=None):
+        self.engine = engine
+        self.always_exchange = False  # run the collectives even at world size 1 (tests)
+        self.num_vertices = int(num_vertices)
+        self.rank, self.world, self.group = rank, world, group
+        self.first, self.last, self.chunk = partition_bounds(self.num_vertices, world, rank)
+        self.graph = None
+        self.out_w = None  # out-weight sums of the local vertices (float64)
+        self.value_dtype = None
+        self.vertex_dtype = None
+        self.t_generate = 0.0
+        self.t_build = 0.0
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_edges(cls, engine, src, dst, wgt, num_vertices, *, rank=None, world=None, group=None):
+        """src/dst/wgt: this rank's ARBITRARY share of the global edge list (as each Dask worker
+        holds in the reference)."""
+        import torch
+
+        dist = _dist()
+        rank = dist.get_rank(group) if rank is None else rank
+        world = dist.get_world_size(group) if world is None else world
+        self = cls(engine, num_vertices, rank, world, group)
+        t0 = time.perf_counter()
+        self.vertex_dtype = src.dtype
+        self.value_dtype = torch.float32 if wgt is None else wgt.dtype
+        if world > 1:
+            src, dst, wgt = shuffle_edges_to_owner(src, dst, wgt, self.chunk, world, group)
+        self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last,
+                                             self.num_vertices)
+        del src, dst, wgt
+        sums = engine.source_weight_sums(self.graph, self.num_vertices)
+        if world > 1:
+            dist.all_reduce(sums, group=group)
+        self.out_w = sums[self.first:self.last].clone()
+        del sums
+        self.t_build = time.perf_counter() - t0
+        return self
+
+    @classmethod
+    def from_rmat(cls, resource_handle, graph_properties, scale, num_edges, *, seed=42,
+                  scramble_vertex_ids=True, weighted=False, group=None):
+        """Every rank generates its slice of the R-MAT edge stream on its own GPU."""
+        import torch
+
+        from . import generators
+
+        dist = _dist()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        per = (num_edges + world - 1) // world
+        e0 = min(rank * per, num_edges)
+        n = min(per, num_edges - e0)
+        t0 = time.perf_counter()
+        src, dst = generators.rmat(resource_handle, scale, n, seed=seed,
+                                   scramble_vertex_ids=scramble_vertex_ids, first_edge=e0)
+        wgt = generators.rmat_weights(resource_handle, n, seed=seed + 1, first_edge=e0) if weighted else None
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t0
+        self = cls.from_edges(HipEngine(resource_handle, graph_properties), src, dst, wgt,
+                              1 << scale, rank=rank, world=world, group=group)
+        self.t_generate = t_gen
+        return self
+
+    # ------------------------------------------------------------------ sessions
+    def _local_pairs(self, vertices, values, scale=1.0):
+        """Keep the (vertex, value) pairs this rank owns; inputs are replicated on every rank."""
+        import torch
+
+        v = torch.as_tensor(vertices, device=self.engine.device).to(self.vertex_dtype)
+        x = torch.as_tensor(values, device=self.engine.device).to(torch.float64)
+        keep = (v >= self.first) & (v < self.last)
+        return v[keep].contiguous(), (x[keep] / scale).to(self.value_dtype).contiguous()
+
+    def session(self, *, alpha=0.85, epsilon=1e-6, nstart=None, personalization=None):
+        """nstart / personalization: optional (vertices, values) pairs, the SAME on every rank.
+        Personalization values are divided by their global sum here (the library normalises only
+        what it can see, pagerank_impl.cuh:213-226)."""
+        import torch
+
+        ids = torch.arange(self.first, self.last, device=self.engine.device).to(self.vertex_dtype)
+        kw = dict(alpha=alpha, epsilon=epsilon,
+                  precomputed_vertex_out_weight_vertices=ids,
+                  precomputed_vertex_out_weight_sums=self.out_w.to(self.value_dtype))
+        if nstart is not None:
+            gv, gx = self._local_pairs(*nstart)
+            kw.update(initial_guess_vertices=gv, initial_guess_values=gx)
+        if personalization is not None:
+            total = float(torch.as_tensor(personalization[1]).to(torch.float64).sum())
+            if not total > 0.0:
+                raise ValueError("Invalid input argument: sum of personalization values should be positive.")
+            pv, px = self._local_pairs(personalization[0], personalization[1], scale=total)
+            kw.update(personalization_vertices=pv, personalization_values=px)
+        sess = MGSession(self.engine.make_session(self.graph, **kw))
+        self._exchange(sess)  # x0 and the dangling mass of pr0
+        return sess
+
+    def _exchange(self, sess):
+        if self.world == 1 and not self.always_exchange:
+            return
+        x_full, scal = sess.inner.exchange_buffers()
+        all_gather_in_place(x_full, self.chunk, self.rank, self.world, self.group)
+        _dist().all_reduce(scal, group=self.group)
+
+    def iterate(self, sess, n=1):
+        for _ in range(n):
+            sess.inner.iterate(1)
+            self._exchange(sess)
+
+    def timed_iterate(self, sess, n):
+        it, km = [], []
+        for _ in range(n):
+            a, b = sess.inner.timed_iterate(1)
+            self._exchange(sess)
+            it.append(a[0])
+            km.append(b[0])
+        return np.array(it), np.array(km)
+
+    def run_to_convergence(self, sess, max_iterations, check_every=4):
+        """Returns (iterations, stopped, l1_delta).  At least one iteration runs
+        (pagerank_impl.cuh:235-335)."""
+        budget = max(int(max_iterations), 1)
+        done = 0
+        iters, stopped, delta = 0, False, float("inf")
+        while done < budget:
+            n = min(check_every, budget - done)
+            for _ in range(n):
+                sess.inner.iterate(1)
+                self._exchange(sess)
+            done += n
+            iters, stopped, delta, _ = sess.inner.status()
+            if stopped:
+                break
+        return iters, stopped, delta
+
+    def result(self, sess, max_iterations):
+        """(local vertex ids, local ranks, iterations, converged) -- per-rank slices, as the
+        reference returns per worker (dask/link_analysis/pagerank.py:426-427)."""
+        return sess.inner.result(max_iterations)
+
+    def gathered_result(self, sess, max_iterations):
+        """Every rank gets the full rank vector (tests / small graphs)."""
+        import torch
+
+        verts, vals, iters, conv = self.result(sess, max_iterations)
+        if self.world == 1:
+            return vals, iters, conv
+        full = torch.zeros(self.chunk * self.world, dtype=vals.dtype, device=vals.device)
+        full[self.first:self.last] = vals
+        all_gather_in_place(full, self.chunk, self.rank, self.world, self.group)
+        return full[:self.num_vertices], iters, conv
+
+
+def pagerank(resource_handle, graph_properties, src, dst, wgt, num_vertices, *, alpha=0.85,
+             tol=1.0e-5, max_iter=100, nstart=None, personalization=None,
+             fail_on_nonconvergence=True, group=None):
+    """cugraph.dask.pagerank-shaped convenience call (dask/link_analysis/pagerank.py:174-183):
+    returns this rank's (vertices, pageranks[, converged])."""
+    from .pylibcugraph.exceptions import FailedToConvergeError
+
+    drv = MGPagerank.from_edges(HipEngine(resource_handle, graph_properties), src, dst, wgt,
+                                num_vertices, group=group)
+    sess = drv.session(alpha=alpha, epsilon=tol, nstart=nstart, personalization=personalization)
+    drv.run_to_convergence(sess, max_iter)
+    verts, vals, iters, conv = drv.result(sess, max_iter)
+    if fail_on_nonconvergence:
+        if not conv:
+            raise FailedToConvergeError
+        return verts, vals
+    return verts, vals, conv

@@ -1,0 +1,106 @@
+"""CPU stand-in for cugraph_amd.mg.HipEngine, used ONLY by the world_size-2 gloo tests.
+
+It restates, with numpy on one partition, what the HIP session does between two collectives
+(cugraph_amd/csrc/pagerank.hip: prep/spmv/pers/finalize kernels and the device-side stop rule), so
+that the distributed driver -- partition bounds, edge routing, the out-weight all-reduce, the
+all-gather / all-reduce per iteration, personalization routing, result assembly -- runs end to end
+without a GPU.  Test infrastructure; never imported by the package.
+"""
+import numpy as np
+import torch
+
+
+class _Graph:
+    def __init__(self, src, dst, wgt, first, last, num_global):
+        self.first, self.last, self.num_global = first, last, num_global
+        self.src = src.numpy().astype(np.int64)
+        self.dst = dst.numpy().astype(np.int64)
+        self.wgt = None if wgt is None else wgt.numpy().astype(np.float64)
+        assert np.all((self.dst >= first) & (self.dst < last)), "edge routed to the wrong rank"
+
+
+class _Session:
+    def __init__(self, g, world, rank, alpha, epsilon, out_w_v, out_w, guess_v=None, guess_x=None,
+                 pers_v=None, pers_x=None):
+        self.g, self.alpha, self.eps = g, alpha, epsilon
+        nl = g.last - g.first
+        chunk = (g.num_global + world - 1) // world
+        assert g.first == min(rank * chunk, g.num_global)
+        self.out_w = np.zeros(nl)
+        self.out_w[out_w_v.numpy() - g.first] = out_w.numpy()
+        self.pr = np.full(nl, 1.0 / g.num_global)
+        if guess_v is not None:
+            self.pr = np.zeros(nl)
+            self.pr[guess_v.numpy() - g.first] = guess_x.numpy()
+        self.pers = None
+        if pers_v is not None:
+            self.pers = np.zeros(nl)
+            np.add.at(self.pers, pers_v.numpy() - g.first, pers_x.numpy())  # already normalised
+        self.x = [torch.zeros(chunk * world, dtype=torch.float64) for _ in range(2)]
+        self.scal = torch.zeros(2, dtype=torch.float64)
+        self.enqueued, self.iters, self.done = 0, 0, False
+        dang = self.out_w == 0
+        xs = np.where(dang, self.pr, self.pr / np.where(dang, 1.0, self.out_w))
+        self.x[0][g.first:g.last] = torch.from_numpy(xs)
+        self.scal[0] = float(self.pr[dang].sum())
+        self.scal[1] = 1e300
+
+    def iterate(self, n=1):
+        g = self.g
+        for _ in range(n):
+            cur, nxt = self.enqueued & 1, (self.enqueued & 1) ^ 1
+            self.enqueued += 1
+            if self.done:
+                continue
+            if float(self.scal[1]) < self.eps:
+                self.done = True
+                continue
+            x = self.x[cur].numpy()
+            contrib = x[g.src] * (1.0 if g.wgt is None else g.wgt)
+            acc = np.bincount(g.dst - g.first, weights=contrib, minlength=g.last - g.first)
+            teleport = float(self.scal[0]) * self.alpha + (1.0 - self.alpha)
+            base = 0.0 if self.pers is not None else teleport / g.num_global
+            pr = base + self.alpha * acc
+            if self.pers is not None:
+                pr = pr + teleport * self.pers
+            dang = self.out_w == 0
+            self.scal[1] = float(np.abs(pr - self.pr).sum())
+            self.scal[0] = float(pr[dang].sum())
+            xs = np.where(dang, pr, pr / np.where(dang, 1.0, self.out_w))
+            self.x[nxt][g.first:g.last] = torch.from_numpy(xs)
+            self.pr = pr
+            self.iters += 1
+
+    def exchange_buffers(self):
+        return self.x[self.enqueued & 1], self.scal
+
+    def status(self):
+        stopped = self.done or (self.iters > 0 and float(self.scal[1]) < self.eps)
+        return self.iters, stopped, float(self.scal[1]), float(self.scal[0])
+
+    def result(self, max_iterations):
+        verts = torch.arange(self.g.first, self.g.last, dtype=torch.int64)
+        return verts, torch.from_numpy(self.pr.copy()), self.iters, self.iters < max_iterations
+
+
+class OracleEngine:
+    device = "cpu"
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def make_local_graph(self, src, dst, wgt, first, last, num_global):
+        return _Graph(src, dst, wgt, first, last, num_global)
+
+    def source_weight_sums(self, graph, num_global):
+        w = np.ones(len(graph.src)) if graph.wgt is None else graph.wgt
+        return torch.from_numpy(np.bincount(graph.src, weights=w, minlength=num_global))
+
+    def make_session(self, graph, *, alpha, epsilon, precomputed_vertex_out_weight_vertices,
+                     precomputed_vertex_out_weight_sums, initial_guess_vertices=None,
+                     initial_guess_values=None, personalization_vertices=None,
+                     personalization_values=None):
+        return _Session(graph, self.world, self.rank, alpha, epsilon,
+                        precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums,
+                        initial_guess_vertices, initial_guess_values, personalization_vertices,
+                        personalization_values)

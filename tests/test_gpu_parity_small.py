@@ -263,3 +263,39 @@ def test_nstart_and_precomputed_out_weights(relabel, monkeypatch):
     assert conv == o_conv
     assert np.array_equal(v.cpu().numpy(), np.arange(nv))
     assert np.max(np.abs(r.cpu().numpy() - o_pr)) <= 1e-6
+
+
+def test_mg_driver_on_one_gpu():
+    """The multi-GPU driver with its HIP engine and RCCL collectives, one rank: 1D-partitioned
+    local graph, out-weight all-reduce, in-place all-gather of x, 2-scalar all-reduce."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from cugraph_amd import mg, pylibcugraph as plc
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        scale = 13
+        nv, ne = 1 << scale, 16 << scale
+        h = plc.ResourceHandle(rank=0, comm_size=1)
+        drv = mg.MGPagerank.from_rmat(h, plc.GraphProperties(is_multigraph=True), scale, ne,
+                                      seed=42, scramble_vertex_ids=True)
+        drv.always_exchange = True
+        eps = nv * 1e-8
+        sess = drv.session(alpha=0.85, epsilon=eps)
+        iters, stopped, _ = drv.run_to_convergence(sess, 500)
+        full, it2, conv = drv.gathered_result(sess, 500)
+        src, dst = oracle.rmat_edges(scale, ne, seed=42, scramble=True)
+        off, idx, _ = oracle.compress(nv, dst, src)
+        o_pr, o_it, _ = oracle.pagerank(nv, off, idx, None, dtype=np.float64, alpha=0.85,
+                                        epsilon=eps, max_iterations=500)
+        assert stopped and conv and iters == o_it == it2
+        assert np.max(np.abs(full.cpu().numpy() - o_pr)) <= 1e-6
+    finally:
+        if own:
+            dist.destroy_process_group()

@@ -1,0 +1,131 @@
+"""world_size-2 (and 3) runs of the multi-GPU driver on CPU over gloo.
+
+The local compute is the numpy test double (tests/mg_test_double.py); what is under test is
+cugraph_amd/mg.py: 1D partition bounds, routing of edges to the owner of their destination, the
+all-reduce of out-weight sums, the per-iteration all-gather + 2-scalar all-reduce, the stop rule
+(same iteration count on every rank, equal to the single-process oracle) and result assembly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, out_dir):
+    import torch.distributed as dist
+
+    from cugraph_amd import mg
+    from mg_test_double import OracleEngine
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src, dst, wgt, nv = case["src"], case["dst"], case["wgt"], case["nv"]
+        # every rank starts with an arbitrary share of the edge list (round-robin here)
+        sel = np.arange(len(src)) % world == rank
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a[sel]))  # noqa: E731
+        drv = mg.MGPagerank.from_edges(OracleEngine(rank, world), t(src), t(dst), t(wgt), nv,
+                                       rank=rank, world=world)
+        first, last, chunk = mg.partition_bounds(nv, world, rank)
+        assert (drv.first, drv.last) == (first, last)
+        assert drv.graph.first == first and len(drv.out_w) == last - first
+        sess = drv.session(alpha=0.85, epsilon=case["eps"], nstart=case.get("nstart"),
+                           personalization=case.get("pers"))
+        iters, stopped, _ = drv.run_to_convergence(sess, case["max_iter"], check_every=case["check"])
+        full, it2, conv = drv.gathered_result(sess, case["max_iter"])
+        verts, vals, _, _ = drv.result(sess, case["max_iter"])
+        assert verts.tolist() == list(range(first, last)) and len(vals) == last - first
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), full.numpy())
+        np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([iters, it2, int(stopped), int(conv)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, case, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    fulls = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
+    metas = [np.load(tmp_path / f"meta{r}.npy") for r in range(world)]
+    return fulls, metas
+
+
+def _oracle(case):
+    import oracle
+
+    nv = case["nv"]
+    off, idx, perm = oracle.compress(nv, case["dst"], case["src"])
+    w = None if case["wgt"] is None else case["wgt"][perm]
+    kw = {}
+    if case.get("nstart") is not None:
+        ns = np.zeros(nv)
+        ns[case["nstart"][0]] = case["nstart"][1]
+        kw["nstart"] = ns
+    if case.get("pers") is not None:
+        kw["pers_vertices"], kw["pers_values"] = case["pers"]
+    return oracle.pagerank(nv, off, idx, w, dtype=np.float64, alpha=0.85, epsilon=case["eps"],
+                           max_iterations=case["max_iter"], **kw)
+
+
+def _rmat_case(scale, weighted, **extra):
+    import oracle
+
+    nv, ne = 1 << scale, 8 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=7, scramble=True)
+    wgt = oracle.rmat_weights(ne, seed=8) if weighted else None
+    case = dict(src=src.astype(np.int64), dst=dst.astype(np.int64), wgt=wgt, nv=nv, eps=nv * 1e-9,
+                max_iter=200, check=3)
+    case.update(extra)
+    return case
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_mg_matches_single_process_oracle(world, weighted, tmp_path):
+    case = _rmat_case(9, weighted)
+    fulls, metas = _run(world, case, tmp_path)
+    o_pr, o_it, o_conv = _oracle(case)
+    for f, m in zip(fulls, metas):
+        assert m[0] == o_it and m[1] == o_it  # same iteration on every rank as the oracle
+        assert bool(m[2]) and bool(m[3]) == o_conv
+        assert np.max(np.abs(f - o_pr)) < 1e-12
+    assert abs(fulls[0].sum() - 1.0) < 1e-9
+
+
+def test_mg_personalization_nstart_and_nonconvergence(tmp_path):
+    rng = np.random.default_rng(0)
+    nv = 1 << 9
+    pers = (rng.permutation(nv)[:37].astype(np.int64), rng.random(37) + 0.1)  # un-normalised
+    nstart = (rng.permutation(nv)[:300].astype(np.int64), rng.random(300))
+    case = _rmat_case(9, True, pers=pers, nstart=nstart, max_iter=4, eps=1e-30, check=1)
+    fulls, metas = _run(2, case, tmp_path)
+    o_pr, o_it, o_conv = _oracle(case)
+    assert o_it == 4 and not o_conv
+    for f, m in zip(fulls, metas):
+        assert m[0] == 4 and not bool(m[3])
+        assert np.max(np.abs(f - o_pr)) < 1e-12
+
+
+def test_partition_bounds_cover_everything():
+    from cugraph_amd import mg
+
+    for nv in (0, 1, 7, 8, 9, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [mg.partition_bounds(nv, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == nv
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0] and a[2] == b[2]
+            assert all(last - first <= chunk for first, last, chunk in spans)
