@@ -191,6 +191,7 @@ struct CompressedOut {
   DevBuf offsets;  // int32 or int64
   DevBuf indices;  // int32
   DevBuf weights;  // weight type or empty
+  DevBuf perm;     // uint32 input position per stored edge (compress_coo_perm only)
   bool off64{false};
 };
 
@@ -204,6 +205,9 @@ CompressedOut compress_coo(hipStream_t stream,
                            int32_t const* minors,
                            void const* weights,
                            size_t weight_size);
+
+CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_minor,
+                                int64_t n_edges, int32_t const* majors, int32_t const* minors);
 
 // offsets -> one major id per edge (the inverse of the histogram+scan)
 void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,

@@ -400,6 +400,17 @@ __global__ void unpack_weighted_kernel(unsigned long long const* __restrict__ ke
   }
 }
 
+__global__ void unpack_perm_kernel(unsigned long long const* __restrict__ keys, int64_t n,
+                                   int32_t* __restrict__ indices, uint32_t* __restrict__ perm)
+{
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned long long k = keys[i];
+    indices[i]           = static_cast<int32_t>(k >> 32);
+    perm[i]              = static_cast<uint32_t>(k);
+  }
+}
+
 template <typename OffT>
 __global__ void expand_offsets_kernel(OffT const* __restrict__ offsets, int64_t n_major,
                                       int64_t n_edges, int32_t* __restrict__ majors)
@@ -478,13 +489,19 @@ void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t 
 template <typename OffT>
 CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                             int32_t const* majors, int32_t const* minors, void const* weights,
-                            size_t weight_size)
+                            size_t weight_size, bool want_perm = false)
 {
   CompressedOut out;
   out.off64 = sizeof(OffT) == 8;
   out.offsets.alloc(static_cast<size_t>(n_major + 1) * sizeof(OffT));
-  out.indices.alloc(static_cast<size_t>(n_edges > 0 ? n_edges : 1) * sizeof(int32_t));
-  if (weights) out.weights.alloc(static_cast<size_t>(n_edges > 0 ? n_edges : 1) * weight_size);
+  // +4 elements: the SpMV reads 16-byte aligned vectors and may touch up to 3 elements past the end
+  out.indices.alloc(static_cast<size_t>(n_edges + 4) * sizeof(int32_t));
+  CGA_HIP(hipMemsetAsync(out.indices.as<char>() + static_cast<size_t>(n_edges) * 4, 0, 16, stream));
+  if (weights) {
+    out.weights.alloc(static_cast<size_t>(n_edges + 4) * weight_size);
+    CGA_HIP(hipMemsetAsync(out.weights.as<char>() + static_cast<size_t>(n_edges) * weight_size, 0,
+                           4 * weight_size, stream));
+  }
 
   DevBuf counts(static_cast<size_t>(n_major > 0 ? n_major : 1) * sizeof(unsigned int));
   CGA_HIP(hipMemsetAsync(counts.p, 0, counts.bytes, stream));
@@ -505,7 +522,22 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
 
   if (n_edges > 0) {
     CGA_HIP(hipMemsetAsync(counts.p, 0, counts.bytes, stream));
-    if (weights) {
+    if (want_perm) {
+      CGA_EXPECTS(n_edges <= 0xffffffffLL, CUGRAPH_NOT_IMPLEMENTED, "2^32 or more edges");
+      out.perm.alloc(static_cast<size_t>(n_edges + 4) * sizeof(uint32_t));
+      DevBuf keys(static_cast<size_t>(n_edges) * sizeof(unsigned long long));
+      hipLaunchKernelGGL((scatter_kernel<OffT, unsigned long long>), dim3(grid_for(n_edges)),
+                         dim3(kThreads), 0, stream, majors, minors, n_edges, out.offsets.as<OffT>(),
+                         counts.as<unsigned int>(), keys.as<unsigned long long>());
+      order_columns<OffT, unsigned long long>(stream, out.offsets.as<OffT>(),
+                                              keys.as<unsigned long long>(), n_major, n_minor,
+                                              n_edges);
+      hipLaunchKernelGGL(unpack_perm_kernel, dim3(grid_for(n_edges)), dim3(kThreads), 0, stream,
+                         keys.as<unsigned long long>(), n_edges, out.indices.as<int32_t>(),
+                         out.perm.as<uint32_t>());
+      CGA_HIP(hipGetLastError());
+      CGA_HIP(hipStreamSynchronize(stream));
+    } else if (weights) {
       CGA_EXPECTS(n_edges <= 0xffffffffLL, CUGRAPH_NOT_IMPLEMENTED,
                   "weighted graphs with 2^32 or more edges per GPU are not supported");
       DevBuf keys(static_cast<size_t>(n_edges) * sizeof(unsigned long long));
@@ -607,6 +639,15 @@ Graph::~Graph()
   if (number_map) (void)hipFree(number_map);
   if (ext_lookup) (void)hipFree(ext_lookup);
   if (plan) destroy_plan(plan);
+}
+
+// as compress_coo, without weights, plus perm[k] = input position of the edge stored at k
+CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_minor,
+                                int64_t n_edges, int32_t const* majors, int32_t const* minors)
+{
+  if (n_edges < 0x7fffffffLL)
+    return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true);
+  return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true);
 }
 
 void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,

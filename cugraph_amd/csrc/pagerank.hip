@@ -37,8 +37,39 @@ namespace cga {
 namespace {
 
 constexpr int kThreads     = 256;
-constexpr int kNumBuckets  = 4;
-constexpr int kMaxPartials = 8192;
+constexpr int kNumBuckets  = 5;  // hub items, wave64, 16-lane, 4-lane, thread per vertex
+constexpr int kMaxPartials = 16384;
+constexpr int64_t kHubChunk = 32768;  // edges of one hub work item (longer columns are split)
+
+// XS ("XCD-sliced, source-sorted") tiles for the mid-degree rows: see the comment at xs_bucket
+constexpr int kXsSlices       = 8;      // one slice of the source ids per XCD
+constexpr int64_t kXsTileEdges = 1 << 20;  // a tile is a run of rows holding about this many edges,
+constexpr int kXsMaxRows      = 4096;     // but never more than this many rows (LDS accumulators)
+constexpr int kXsMinDegree    = 16;
+constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
+
+__host__ __device__ inline uint32_t xs_slice_of(uint32_t src) { return (src >> 5) & (kXsSlices - 1); }
+
+template <typename ValT>
+struct XsArgs {
+  int32_t const* src;        // [n_edges + 4] sources, ascending inside each (tile, slice) unit
+  uint16_t const* rowl;      // [n_edges + 4] row of the entry, relative to its tile's first row
+  ValT const* w;             // [n_edges + 4] or nullptr
+  int64_t const* unit_off;   // [n_tiles * 8 + 1]
+  int32_t const* tile_row;   // [n_tiles + 1] first row of each tile, relative to row_first
+  ValT* partial;             // [8][n_rows] per-slice partial sums
+  int* counters;             // [8] next tile of each slice's queue
+  int64_t row_first, n_rows;
+  int n_tiles;
+  int block_begin, n_blocks;
+  int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
+};
+
+// one piece of a hub column; its partial sum lands in item_partial[item]
+struct HubItem {
+  int64_t beg;
+  int64_t end;
+};
 
 struct Ctrl {
   unsigned long long iters;
@@ -73,9 +104,20 @@ struct IterArgs {
   ValT num_vertices;  // global vertex count as a value
   double epsilon;
   int personalized;
+  uint32_t gather_mask;  // 0xFFFFFFFF; a timing aid can narrow it (CUGRAPH_AMD_GATHER_MASK)
   int64_t vertex_first;
+  HubItem const* hub_items;  // bucket 0 works on these instead of whole rows
+  int64_t n_hub_items;
+  double* hub_item_partial;
+  XsArgs<ValT> xs;
   Bucket buckets[kNumBuckets];
 };
+
+__device__ inline uint32_t xcc_id()
+{
+  // HW_REG_XCC_ID (20), bits [3:0]: which XCD this wave runs on.  Used for L2 affinity only.
+  return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+}
 
 template <typename T>
 __device__ inline T group_sum(T v, int width)
@@ -146,55 +188,224 @@ __device__ inline void write_partials(double dangling, double delta, double* par
   }
 }
 
-// G lanes cooperate on one destination vertex
+__device__ inline void load4(float const* p, float* w)
+{
+  float4 v = *reinterpret_cast<float4 const*>(p);
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+__device__ inline void load4(double const* p, double* w)
+{
+  double2 v0 = *reinterpret_cast<double2 const*>(p);
+  double2 v1 = *reinterpret_cast<double2 const*>(p + 2);
+  w[0] = v0.x; w[1] = v0.y; w[2] = v1.x; w[3] = v1.y;
+}
+
+// Partial sum of x[src]*w over edges [beg, end) of one column for one of G cooperating lanes.
+// Every lane loads 16-byte vectors of 4 consecutive indices at 16-byte aligned positions (lane
+// stride 16 B: a wave reads 1 KiB per instruction, fully coalesced) and issues the 4 (x2) gathers
+// back to back, so each lane keeps 8 independent gathers in flight.  The arrays are padded so the
+// aligned over-read past the last edge stays inside the allocation (graph_build.hip).
+template <int G, typename OffT, typename ValT, bool WEIGHTED>
+__device__ inline double column_partial(IterArgs<OffT, ValT> const& a, OffT beg, OffT end, int lane)
+{
+  double acc     = 0.0;
+  OffT const step = static_cast<OffT>(G) * 4;
+  for (OffT j = (beg & ~static_cast<OffT>(3)) + static_cast<OffT>(lane) * 4; j < end; j += 2 * step) {
+    OffT j2  = j + step;
+    bool two = j2 < end;
+    int4 q   = *reinterpret_cast<int4 const*>(a.indices + j);
+    int4 r   = two ? *reinterpret_cast<int4 const*>(a.indices + j2) : int4{0, 0, 0, 0};
+    ValT w[8];
+    if constexpr (WEIGHTED) {
+      load4(a.weights + j, w);
+      if (two) {
+        load4(a.weights + j2, w + 4);
+      } else {
+        w[4] = w[5] = w[6] = w[7] = ValT(0);
+      }
+    }
+    bool p[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      p[k]     = (j + k >= beg) && (j + k < end);
+      p[4 + k] = two && (j2 + k < end);  // j2 + k > beg always
+    }
+    uint32_t gi[8] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w,
+                      (uint32_t)r.x, (uint32_t)r.y, (uint32_t)r.z, (uint32_t)r.w};
+    ValT xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[k] = p[k] ? a.x_cur[gi[k] & a.gather_mask] : ValT(0);
+    if constexpr (WEIGHTED) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xv[k] *= w[k];
+    }
+    ValT s0 = (xv[0] + xv[1]) + (xv[2] + xv[3]);
+    ValT s1 = (xv[4] + xv[5]) + (xv[6] + xv[7]);
+    acc += static_cast<double>(s0) + static_cast<double>(s1);
+  }
+  return acc;
+}
+
+// G lanes cooperate on one destination vertex (G = 64: one wave64 per vertex)
 template <int G, typename OffT, typename ValT, bool WEIGHTED>
 __device__ inline void group_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b,
                                     Epilogue<OffT, ValT>& ep)
 {
-  using AccT       = typename std::conditional<(G > 1), double, ValT>::type;
   int lane         = threadIdx.x & (G - 1);
   int64_t group    = ((int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x) / G;
   int64_t n_groups = ((int64_t)b.n_blocks * kThreads) / G;
   for (int64_t i = group; i < b.count; i += n_groups) {
     int64_t v = b.list ? static_cast<int64_t>(b.list[i]) : b.first + i;
     OffT beg = a.offsets[v], end = a.offsets[v + 1];
-    AccT acc = 0;
-#pragma unroll 4
-    for (OffT j = beg + lane; j < end; j += G) {
-      ValT xv = a.x_cur[a.indices[j]];
-      if constexpr (WEIGHTED) xv *= a.weights[j];
-      acc += static_cast<AccT>(xv);
-    }
-    if constexpr (G > 1) acc = group_sum(acc, G);
+    double acc = column_partial<G, OffT, ValT, WEIGHTED>(a, beg, end, lane);
+    acc        = group_sum(acc, G);
     if (lane == 0) ep.finish(v, static_cast<ValT>(acc));
   }
 }
 
-// one workgroup per hub: threads stride the column (coalesced), partial sums staged through LDS
+// thread per vertex, for the shortest columns (deg < 4)
 template <typename OffT, typename ValT, bool WEIGHTED>
-__device__ inline void hub_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b,
-                                  Epilogue<OffT, ValT>& ep)
+__device__ inline void thread_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b,
+                                     Epilogue<OffT, ValT>& ep)
 {
-  __shared__ double hub_lds[kThreads / 64];
-  for (int64_t i = blockIdx.x - b.block_begin; i < b.count; i += b.n_blocks) {
+  int64_t t = (int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x;
+  int64_t n = (int64_t)b.n_blocks * kThreads;
+  for (int64_t i = t; i < b.count; i += n) {
     int64_t v = b.list ? static_cast<int64_t>(b.list[i]) : b.first + i;
     OffT beg = a.offsets[v], end = a.offsets[v + 1];
-    double acc = 0.0;
-#pragma unroll 4
-    for (OffT j = beg + threadIdx.x; j < end; j += kThreads) {
-      ValT xv = a.x_cur[a.indices[j]];
+    ValT acc = 0;
+    for (OffT j = beg; j < end; ++j) {
+      ValT xv = a.x_cur[static_cast<uint32_t>(a.indices[j]) & a.gather_mask];
       if constexpr (WEIGHTED) xv *= a.weights[j];
-      acc += static_cast<double>(xv);
+      acc += xv;
     }
+    ep.finish(v, acc);
+  }
+}
+
+// hubs: one workgroup per work item (a column, or a 32K-edge piece of a longer one); threads
+// stride the piece coalesced, partial sums staged through LDS; hub_finish_kernel adds the pieces
+template <typename OffT, typename ValT, bool WEIGHTED>
+__device__ inline void hub_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b)
+{
+  __shared__ double hub_lds[kThreads / 64];
+  for (int64_t i = blockIdx.x - b.block_begin; i < a.n_hub_items; i += b.n_blocks) {
+    HubItem it = a.hub_items[i];
+    double acc = column_partial<kThreads, OffT, ValT, WEIGHTED>(
+      a, static_cast<OffT>(it.beg), static_cast<OffT>(it.end), threadIdx.x);
     acc = group_sum(acc, 64);
     if ((threadIdx.x & 63) == 0) hub_lds[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
       double s = 0.0;
       for (int w = 0; w < kThreads / 64; ++w) s += hub_lds[w];
-      ep.finish(v, static_cast<ValT>(s));
+      a.hub_item_partial[i] = s;
     }
     __syncthreads();
+  }
+}
+
+__device__ inline void load4u16(uint16_t const* p, uint32_t* r)
+{
+  uint2 v = *reinterpret_cast<uint2 const*>(p);
+  r[0] = v.x & 0xffffu; r[1] = v.x >> 16; r[2] = v.y & 0xffffu; r[3] = v.y >> 16;
+}
+
+// XS tiles.  The gathers of a pull SpMV are bound by two request rates, not by bytes: ~240 G/s
+// for 4-byte gathers that hit L2 and ~55 G/s for the ones that go to the fabric (measured,
+// tools/gather_bench.hip).  Two things cut both counts for the mid-degree rows:
+//   * source ids are cut into 8 interleaved slices (128-byte granules) and the entries of slice k
+//     are processed by workgroups running on XCD k, so each XCD's 4 MiB L2 only ever sees 1/8 of
+//     the gathered vector: the 8 private L2s add up to 32 MiB of distinct hot sources;
+//   * inside a (tile, slice) unit the entries of MANY rows are stored together in ascending
+//     source order, so the 64 lanes of a gather instruction touch neighbouring sources and the
+//     texture path merges them into a few cache-line requests.
+// Row sums are accumulated with LDS atomics (fp64) per tile and written as one partial per
+// (slice, row); xs_finish_kernel adds the 8 partials and runs the epilogue.  Workgroups pull
+// tiles from the queue of the XCD they run on (HW_REG_XCC_ID) and steal from the other queues
+// when theirs is empty, so the result never depends on where a workgroup was placed.
+template <typename OffT, typename ValT, bool WEIGHTED>
+__device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
+{
+  using XsAcc = double;
+  __shared__ XsAcc acc[kXsMaxRows];
+  __shared__ int s_tile;
+  XsArgs<ValT> const& xs = a.xs;
+  int const tid = threadIdx.x;
+  int const my  = xs.affinity_mode == 0   ? static_cast<int>(xcc_id() & (kXsSlices - 1))
+                  : xs.affinity_mode == 1 ? static_cast<int>(blockIdx.x & (kXsSlices - 1))
+                                          : static_cast<int>((blockIdx.x >> 3) & (kXsSlices - 1));
+  for (int rot = 0; rot < kXsSlices; ++rot) {
+    int const k = (my + rot) & (kXsSlices - 1);
+    while (true) {
+      if (tid == 0) s_tile = atomicAdd(&xs.counters[k], 1);
+      __syncthreads();
+      int const t = s_tile;
+      __syncthreads();
+      if (t >= xs.n_tiles) break;
+      int const row0 = xs.tile_row[t];
+      int const rows = xs.tile_row[t + 1] - row0;
+      for (int i = tid; i < rows; i += kThreads) acc[i] = 0;
+      __syncthreads();
+      int64_t const beg = xs.unit_off[(int64_t)t * kXsSlices + k];
+      int64_t const end = xs.unit_off[(int64_t)t * kXsSlices + k + 1];
+      // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
+      // so every lane keeps the 4 row sums in registers and the block reduces them at the end
+      bool const few = rows <= 4;
+      double racc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int64_t j = (beg & ~int64_t(3)) + (int64_t)tid * 4; j < end; j += 2 * kThreads * 4) {
+        int64_t j2 = j + kThreads * 4;
+        bool two   = j2 < end;
+        int4 q     = *reinterpret_cast<int4 const*>(xs.src + j);
+        int4 r     = two ? *reinterpret_cast<int4 const*>(xs.src + j2) : int4{0, 0, 0, 0};
+        uint32_t rl[8];
+        load4u16(xs.rowl + j, rl);
+        if (two) load4u16(xs.rowl + j2, rl + 4);
+        ValT w[8];
+        if constexpr (WEIGHTED) {
+          load4(xs.w + j, w);
+          if (two) load4(xs.w + j2, w + 4);
+        }
+        uint32_t gi[8] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w,
+                          (uint32_t)r.x, (uint32_t)r.y, (uint32_t)r.z, (uint32_t)r.w};
+        bool p[8];
+        ValT xv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p[e]     = (j + e >= beg) && (j + e < end);
+          p[4 + e] = two && (j2 + e < end);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = p[e] ? a.x_cur[gi[e] & a.gather_mask] : ValT(0);
+        if constexpr (WEIGHTED) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] *= w[e];
+        }
+        if (few) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            double v = p[e] ? static_cast<double>(xv[e]) : 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) racc[rr] += rl[e] == (uint32_t)rr ? v : 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (p[e]) atomicAdd(&acc[rl[e]], static_cast<XsAcc>(xv[e]));
+        }
+      }
+      if (few) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          double v = group_sum(racc[rr], 64);
+          if ((tid & 63) == 0 && rr < rows) atomicAdd(&acc[rr], v);
+        }
+      }
+      __syncthreads();
+      ValT* out = xs.partial + (int64_t)k * xs.n_rows + row0;
+      for (int i = tid; i < rows; i += kThreads) out[i] = static_cast<ValT>(acc[i]);
+      __syncthreads();
+    }
   }
 }
 
@@ -204,17 +415,166 @@ __global__ __launch_bounds__(kThreads) void spmv_kernel(IterArgs<OffT, ValT> a)
   if (stop_check(a.ctrl, a.scal, a.epsilon, true)) return;
   Epilogue<OffT, ValT> ep(a);
   int blk = blockIdx.x;
-  // bucket order in the launch: hubs, wave64, 16-lane, thread-per-vertex
+  // order in the launch: hub items, XS tiles, wave64, 16-lane, 4-lane, thread per vertex
   if (blk < a.buckets[0].block_begin + a.buckets[0].n_blocks) {
-    hub_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[0], ep);
+    hub_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[0]);
+  } else if (blk < a.xs.block_begin + a.xs.n_blocks) {
+    xs_bucket<OffT, ValT, WEIGHTED>(a);
   } else if (blk < a.buckets[1].block_begin + a.buckets[1].n_blocks) {
     group_bucket<64, OffT, ValT, WEIGHTED>(a, a.buckets[1], ep);
   } else if (blk < a.buckets[2].block_begin + a.buckets[2].n_blocks) {
     group_bucket<16, OffT, ValT, WEIGHTED>(a, a.buckets[2], ep);
+  } else if (blk < a.buckets[3].block_begin + a.buckets[3].n_blocks) {
+    group_bucket<4, OffT, ValT, WEIGHTED>(a, a.buckets[3], ep);
   } else {
-    group_bucket<1, OffT, ValT, WEIGHTED>(a, a.buckets[3], ep);
+    thread_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[4], ep);
   }
   write_partials(ep.dangling, ep.delta, a.partials);
+}
+
+// epilogue of the hub rows: add the pieces of each column in a fixed order, then the usual update
+template <typename OffT, typename ValT>
+__global__ __launch_bounds__(kThreads) void hub_finish_kernel(IterArgs<OffT, ValT> a,
+                                                              int64_t const* __restrict__ row_item_off,
+                                                              double* __restrict__ partials)
+{
+  if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
+  Epilogue<OffT, ValT> ep(a);
+  Bucket const& b = a.buckets[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < b.count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = b.list ? static_cast<int64_t>(b.list[i]) : b.first + i;
+    double s  = 0.0;
+    for (int64_t k = row_item_off[i]; k < row_item_off[i + 1]; ++k) s += a.hub_item_partial[k];
+    ep.finish(v, static_cast<ValT>(s));
+  }
+  write_partials(ep.dangling, ep.delta, partials);
+}
+
+// epilogue of the XS rows: the 8 per-slice partials of a row, added in a fixed order
+template <typename OffT, typename ValT>
+__global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT> a,
+                                                             double* __restrict__ partials)
+{
+  if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
+  Epilogue<OffT, ValT> ep(a);
+  XsArgs<ValT> const& xs = a.xs;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < xs.n_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kXsSlices; ++k) s += static_cast<double>(xs.partial[(int64_t)k * xs.n_rows + i]);
+    ep.finish(xs.row_first + i, static_cast<ValT>(s));
+  }
+  write_partials(ep.dangling, ep.delta, partials);
+}
+
+// ---- XS build: unit id (tile * 8 + slice) and row of every edge of the XS row range
+template <typename OffT>
+__global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const* __restrict__ indices,
+                                int64_t row_first, int64_t n_rows, int64_t e0,
+                                int32_t const* __restrict__ tile_of_row,
+                                int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge)
+{
+  constexpr int G = 16;
+  int lane        = threadIdx.x & (G - 1);
+  int64_t group   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  int64_t groups  = ((int64_t)gridDim.x * blockDim.x) / G;
+  for (int64_t i = group; i < n_rows; i += groups) {
+    int64_t beg = static_cast<int64_t>(offsets[row_first + i]);
+    int64_t end = static_cast<int64_t>(offsets[row_first + i + 1]);
+    int32_t t   = tile_of_row[i];
+    for (int64_t j = beg + lane; j < end; j += G) {
+      unit[j - e0]        = t * kXsSlices + static_cast<int32_t>(xs_slice_of(static_cast<uint32_t>(indices[j])));
+      row_of_edge[j - e0] = static_cast<int32_t>(i);
+    }
+  }
+}
+
+// A tile is a run of rows: a new one starts whenever a row's first edge falls into a new window
+// of kXsTileEdges edges, and at every kXsMaxRows-th row.  So a tile has at most kXsMaxRows rows
+// and about kXsTileEdges edges (64 rows of 16K edges, or 4096 rows of 16); a longer column simply
+// makes its tile longer.  flags mark the first row of each tile; a scan numbers the tiles.
+template <typename OffT>
+__global__ void xs_break_flags_kernel(OffT const* __restrict__ offsets, int64_t row_first,
+                                      int64_t n_rows, int64_t e0, unsigned int* __restrict__ flags)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t w  = (static_cast<int64_t>(offsets[row_first + i]) - e0) / kXsTileEdges;
+    int64_t wp = i == 0 ? -1 : (static_cast<int64_t>(offsets[row_first + i - 1]) - e0) / kXsTileEdges;
+    flags[i]   = (w != wp || (i % kXsMaxRows) == 0) ? 1u : 0u;
+  }
+}
+
+__global__ void xs_tiles_kernel(unsigned int const* __restrict__ flags,
+                                int64_t const* __restrict__ pos, int64_t n_rows,
+                                int32_t* __restrict__ tile_of_row, int32_t* __restrict__ tile_row)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= n_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i == n_rows) {
+      tile_row[pos[n_rows]] = static_cast<int32_t>(n_rows);
+      continue;
+    }
+    int64_t t      = pos[i] + flags[i] - 1;
+    tile_of_row[i] = static_cast<int32_t>(t);
+    if (flags[i]) tile_row[t] = static_cast<int32_t>(i);
+  }
+}
+
+template <typename OffT, typename UOffT, typename ValT>
+__global__ void xs_payload_kernel(int32_t const* __restrict__ tile_of_row, int64_t e0,
+                                  int64_t n_edges, uint32_t const* __restrict__ perm,
+                                  int32_t const* __restrict__ row_of_edge,
+                                  int32_t const* __restrict__ tile_row,
+                                  ValT const* __restrict__ w_in, UOffT const* __restrict__ unit_off_in,
+                                  int64_t n_units, uint16_t* __restrict__ rowl,
+                                  ValT* __restrict__ w_out, int64_t* __restrict__ unit_off_out)
+{
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_edges;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t e = perm[k];
+    int32_t r  = row_of_edge[e];
+    rowl[k]    = static_cast<uint16_t>(r - tile_row[tile_of_row[r]]);
+    if (w_in) w_out[k] = w_in[e0 + e];
+  }
+  for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u <= n_units;
+       u += (int64_t)gridDim.x * blockDim.x)
+    unit_off_out[u] = static_cast<int64_t>(unit_off_in[u]);
+}
+
+// hub work items: column i of the hub bucket is cut into ceil(deg / kHubChunk) pieces
+template <typename OffT>
+__global__ void hub_item_count_kernel(OffT const* offsets, int32_t const* list, int64_t first,
+                                      int64_t count, unsigned int* n_items)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v   = list ? static_cast<int64_t>(list[i]) : first + i;
+    int64_t base = static_cast<int64_t>(offsets[v]) & ~int64_t(3);  // as hub_item_fill_kernel
+    int64_t span = static_cast<int64_t>(offsets[v + 1]) - base;
+    n_items[i]   = static_cast<unsigned int>((span + kHubChunk - 1) / kHubChunk);
+  }
+}
+
+template <typename OffT>
+__global__ void hub_item_fill_kernel(OffT const* offsets, int32_t const* list, int64_t first,
+                                     int64_t count, int64_t const* row_item_off, HubItem* items)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v   = list ? static_cast<int64_t>(list[i]) : first + i;
+    int64_t beg = static_cast<int64_t>(offsets[v]), end = static_cast<int64_t>(offsets[v + 1]);
+    int64_t k   = row_item_off[i];
+    // pieces start at multiples of 4 edges from the aligned column start, so that every piece's
+    // vector loads stay 16-byte aligned without overlapping its neighbour's
+    int64_t base = beg & ~int64_t(3);
+    for (int64_t p = base; p < end; p += kHubChunk, ++k) {
+      items[k].beg = p < beg ? beg : p;
+      items[k].end = p + kHubChunk < end ? p + kHubChunk : end;
+    }
+  }
 }
 
 // pr' += teleport * p_i for a short personalization list, with the matching corrections of x',
@@ -471,6 +831,14 @@ struct PullPlan {
   int64_t counts[kNumBuckets]{};
   int64_t firsts[kNumBuckets]{};
   bool contiguous{false};  // buckets are row ranges, no index lists
+  // XS tiles over the rows of buckets 1 and 2 (only on a degree-sorted compute graph)
+  bool xs_on{false};
+  int64_t xs_row_first{0}, xs_n_rows{0}, xs_n_edges{0};
+  int xs_n_tiles{0};
+  DevBuf xs_src, xs_rowl, xs_w, xs_unit_off, xs_tile_row;
+  DevBuf hub_items;         // HubItem[n_hub_items]
+  DevBuf hub_row_item_off;  // int64[counts[0] + 1]
+  int64_t n_hub_items{0};
   DevBuf out_w_sums;  // double[num_global_vertices]: per-source weight sums, compute-graph order
   bool have_out_w{false};
   ~PullPlan() { delete internal; }
@@ -481,8 +849,8 @@ void destroy_plan(PullPlan* p) { delete p; }
 namespace {
 
 // [lo, hi) in-degree ranges, launch order: hubs, wave64, 16-lane groups, thread per vertex
-constexpr int64_t kBucketLo[kNumBuckets] = {2048, 48, 6, 0};
-constexpr int64_t kBucketHi[kNumBuckets] = {INT64_MAX, 2048, 48, 6};
+constexpr int64_t kBucketLo[kNumBuckets] = {kXsMaxDegree, 128, kXsMinDegree, 4, 0};
+constexpr int64_t kBucketHi[kNumBuckets] = {INT64_MAX, kXsMaxDegree, 128, kXsMinDegree, 4};
 
 template <typename OffT>
 void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
@@ -512,8 +880,98 @@ void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
                          flags.as<unsigned int>(), pos.as<int64_t>(), plan.lists[b].as<int32_t>());
     }  // total == n: the identity, no list needed
   }
+  // hub work items
+  int64_t nh = plan.counts[0];
+  plan.n_hub_items = 0;
+  if (nh > 0) {
+    int32_t const* list = plan.lists[0].p ? plan.lists[0].as<int32_t>() : nullptr;
+    DevBuf cnt(static_cast<size_t>(nh) * sizeof(unsigned int));
+    plan.hub_row_item_off.alloc(static_cast<size_t>(nh + 1) * sizeof(int64_t));
+    hipLaunchKernelGGL((hub_item_count_kernel<OffT>), dim3(grid_for(nh)), dim3(kThreads), 0, stream,
+                       static_cast<OffT const*>(g.offsets), list, plan.firsts[0], nh,
+                       cnt.as<unsigned int>());
+    exclusive_scan_u32_to_i64(stream, cnt.as<unsigned int>(), nh, plan.hub_row_item_off.as<int64_t>());
+    CGA_HIP(hipMemcpyAsync(&plan.n_hub_items, plan.hub_row_item_off.as<int64_t>() + nh,
+                           sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    CGA_HIP(hipStreamSynchronize(stream));
+    plan.hub_items.alloc(static_cast<size_t>(plan.n_hub_items > 0 ? plan.n_hub_items : 1) * sizeof(HubItem));
+    CGA_HIP(hipMemsetAsync(plan.hub_items.p, 0, plan.hub_items.bytes, stream));
+    hipLaunchKernelGGL((hub_item_fill_kernel<OffT>), dim3(grid_for(nh)), dim3(kThreads), 0, stream,
+                       static_cast<OffT const*>(g.offsets), list, plan.firsts[0], nh,
+                       plan.hub_row_item_off.as<int64_t>(), plan.hub_items.as<HubItem>());
+  }
   CGA_HIP(hipGetLastError());
   CGA_HIP(hipStreamSynchronize(stream));
+}
+
+template <typename OffT, typename ValT>
+void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
+{
+  int64_t row_first = plan.firsts[0];
+  int64_t n_rows    = plan.counts[0] + plan.counts[1] + plan.counts[2];
+  if (n_rows == 0) return;
+  OffT const* offsets = static_cast<OffT const*>(g.offsets);
+  OffT h_off[2];
+  CGA_HIP(hipMemcpyAsync(&h_off[0], offsets + row_first, sizeof(OffT), hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipMemcpyAsync(&h_off[1], offsets + row_first + n_rows, sizeof(OffT), hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  int64_t e0 = static_cast<int64_t>(h_off[0]), ne = static_cast<int64_t>(h_off[1]) - e0;
+  char const* min_env = std::getenv("CUGRAPH_AMD_XS_MIN_EDGES");
+  int64_t min_edges   = min_env ? std::atoll(min_env) : (int64_t(1) << 22);
+  if (ne < min_edges || ne == 0 || ne > 0xffffffffLL) return;
+  DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
+  DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
+  hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
+                     offsets, row_first, n_rows, e0, flags.as<unsigned int>());
+  exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n_rows, pos.as<int64_t>());
+  int64_t n_tiles64 = 0;
+  CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  int n_tiles     = static_cast<int>(n_tiles64);
+  int64_t n_units = static_cast<int64_t>(n_tiles) * kXsSlices;
+  plan.xs_tile_row.alloc(static_cast<size_t>(n_tiles + 1) * 4);
+  hipLaunchKernelGGL(xs_tiles_kernel, dim3(grid_for(n_rows + 1)), dim3(kThreads), 0, stream,
+                     flags.as<unsigned int>(), pos.as<int64_t>(), n_rows,
+                     tile_of_row.as<int32_t>(), plan.xs_tile_row.as<int32_t>());
+  flags.release();
+  pos.release();
+
+  DevBuf unit(static_cast<size_t>(ne) * 4), row_of_edge(static_cast<size_t>(ne) * 4);
+  hipLaunchKernelGGL((xs_label_kernel<OffT>), dim3(grid_for(n_rows * 16)), dim3(kThreads), 0, stream,
+                     offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(),
+                     unit.as<int32_t>(), row_of_edge.as<int32_t>());
+  CGA_HIP(hipGetLastError());
+  CompressedOut c = compress_coo_perm(stream, n_units, g.num_global_vertices, ne, unit.as<int32_t>(),
+                                      g.indices + e0);
+  unit.release();
+  plan.xs_src = std::move(c.indices);
+  plan.xs_rowl.alloc(static_cast<size_t>(ne + 4) * sizeof(uint16_t));
+  CGA_HIP(hipMemsetAsync(plan.xs_rowl.p, 0, plan.xs_rowl.bytes, stream));
+  if (g.weights) {
+    plan.xs_w.alloc(static_cast<size_t>(ne + 4) * sizeof(ValT));
+    CGA_HIP(hipMemsetAsync(plan.xs_w.p, 0, plan.xs_w.bytes, stream));
+  }
+  plan.xs_unit_off.alloc(static_cast<size_t>(n_units + 1) * sizeof(int64_t));
+  auto launch = [&](auto tag) {
+    using UOffT = decltype(tag);
+    hipLaunchKernelGGL((xs_payload_kernel<OffT, UOffT, ValT>), dim3(grid_for(ne)), dim3(kThreads), 0,
+                       stream, tile_of_row.as<int32_t>(), e0, ne, c.perm.as<uint32_t>(),
+                       row_of_edge.as<int32_t>(), plan.xs_tile_row.as<int32_t>(),
+                       static_cast<ValT const*>(g.weights), c.offsets.as<UOffT>(), n_units,
+                       plan.xs_rowl.as<uint16_t>(), plan.xs_w.as<ValT>(),
+                       plan.xs_unit_off.as<int64_t>());
+  };
+  if (c.off64)
+    launch(int64_t{});
+  else
+    launch(int32_t{});
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
+  plan.xs_on        = true;
+  plan.xs_row_first = row_first;
+  plan.xs_n_rows    = n_rows;
+  plan.xs_n_edges   = ne;
+  plan.xs_n_tiles   = n_tiles;
 }
 
 PullPlan& get_plan(Handle const& h, Graph& g)
@@ -533,6 +991,19 @@ PullPlan& get_plan(Handle const& h, Graph& g)
         build_plan_lists<int64_t>(stream, cg, *p);
       else
         build_plan_lists<int32_t>(stream, cg, *p);
+      char const* xs_env = std::getenv("CUGRAPH_AMD_XS");
+      bool want_xs = !(xs_env && xs_env[0] == '0') && p->contiguous &&
+                     cg.num_global_vertices == cg.num_vertices;
+      if (want_xs) {
+        bool f64 = cg.weight_type == FLOAT64;
+        if (cg.off64) {
+          if (f64) build_xs<int64_t, double>(stream, cg, *p);
+          else build_xs<int64_t, float>(stream, cg, *p);
+        } else {
+          if (f64) build_xs<int32_t, double>(stream, cg, *p);
+          else build_xs<int32_t, float>(stream, cg, *p);
+        }
+      }
     } catch (...) {
       delete p;
       throw;
@@ -576,7 +1047,14 @@ struct Session {
   bool personalized{false};
   bool pers_is_dense{false};
   size_t enqueued{0};
-  int n_spmv_blocks{0}, n_pers_blocks{0};
+  int n_spmv_blocks{0}, n_pers_blocks{0}, n_hub_blocks{0};
+  bool xs_on{false};
+  int xs_block_begin{0}, n_xs_blocks{0}, n_xs_finish_blocks{0};
+  DevBuf xs_partial, xs_counters;
+  int64_t n_hub_items{0};
+  HubItem const* hub_items{nullptr};
+  int64_t const* hub_row_item_off{nullptr};
+  DevBuf hub_item_partial;
   Bucket buckets[kNumBuckets]{};
   std::vector<hipEvent_t> events;
   ~Session()
@@ -783,25 +1261,49 @@ void session_setup(Session& s, PagerankArgs const& a)
   int begin = 0;
   // timing aid: CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets (results are then wrong)
   char const* mask_env = std::getenv("CUGRAPH_AMD_BUCKET_MASK");
-  int bucket_mask      = mask_env ? std::atoi(mask_env) : 0xF;
-  int const group_width[kNumBuckets] = {kThreads, 64, 16, 1};
-  int const block_cap[kNumBuckets]   = {1024, 2048, 2048, 2048};
+  int bucket_mask      = mask_env ? std::atoi(mask_env) : 0x1F;
+  int const group_width[kNumBuckets] = {kThreads, 64, 16, 4, 1};
+  int const block_cap[kNumBuckets]   = {4096, 3072, 3072, 2048, 2048};
+  s.xs_on = plan.xs_on && ((bucket_mask >> 5) & 1 || !mask_env);
   for (int b = 0; b < kNumBuckets; ++b) {
     Bucket& bk    = s.buckets[b];
     bk.count      = ((bucket_mask >> b) & 1) ? plan.counts[b] : 0;
+    if (plan.xs_on && b <= 2) bk.count = 0;  // rows with >= kXsMinDegree edges: XS tiles
     bk.list       = plan.lists[b].p ? plan.lists[b].as<int32_t>() : nullptr;
     bk.first      = plan.firsts[b];
     int64_t need  = (bk.count * group_width[b] + kThreads - 1) / kThreads;
+    if (b == 0) need = bk.count > 0 ? plan.n_hub_items : 0;  // one workgroup per hub work item
     bk.n_blocks   = static_cast<int>(std::min<int64_t>(need, block_cap[b]));
     bk.block_begin = begin;
     begin += bk.n_blocks;
+    if (b == 0) {  // XS workgroups come right after the hub items
+      s.xs_block_begin = begin;
+      s.n_xs_blocks    = s.xs_on ? static_cast<int>(std::min<int64_t>(
+                                      static_cast<int64_t>(plan.xs_n_tiles) * kXsSlices,
+                                      std::getenv("CUGRAPH_AMD_XS_BLOCKS")
+                                        ? std::atoi(std::getenv("CUGRAPH_AMD_XS_BLOCKS"))
+                                        : 1024))
+                                 : 0;
+      begin += s.n_xs_blocks;
+    }
+  }
+  if (s.xs_on) {
+    s.xs_partial.alloc(static_cast<size_t>(kXsSlices * plan.xs_n_rows) * vb);
+    s.xs_counters.alloc(256);
+    s.n_xs_finish_blocks = grid_for(plan.xs_n_rows, 1024);
   }
   s.n_spmv_blocks = std::max(begin, 1);
+  s.n_hub_items   = s.buckets[0].count > 0 ? plan.n_hub_items : 0;
+  s.n_hub_blocks  = s.n_hub_items > 0 ? grid_for(s.buckets[0].count, 256) : 0;
+  s.hub_items     = plan.hub_items.p ? plan.hub_items.as<HubItem>() : nullptr;
+  s.hub_row_item_off = plan.hub_row_item_off.p ? plan.hub_row_item_off.as<int64_t>() : nullptr;
+  s.hub_item_partial.alloc(static_cast<size_t>(s.n_hub_items > 0 ? s.n_hub_items : 1) * sizeof(double));
   s.n_pers_blocks = (s.personalized && !s.pers_is_dense && s.n_pers > 0)
                       ? grid_for(s.n_pers, 256)
                       : 0;
   int n_prep_blocks = grid_for(nl, 1024);
-  int n_partials    = std::max(s.n_spmv_blocks + s.n_pers_blocks, n_prep_blocks);
+  int n_partials    = std::max(s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks + s.n_pers_blocks,
+                               n_prep_blocks);
   CGA_EXPECTS(n_partials <= kMaxPartials, CUGRAPH_UNKNOWN_ERROR, "internal: too many partials");
   s.partials.alloc(static_cast<size_t>(2 * n_partials) * sizeof(double));
 
@@ -838,7 +1340,34 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   a.num_vertices    = static_cast<ValT>(s.n_global);
   a.epsilon         = s.epsilon;
   a.personalized    = s.personalized ? 1 : 0;
+  {
+    char const* gm = std::getenv("CUGRAPH_AMD_GATHER_MASK");
+    a.gather_mask  = gm ? static_cast<uint32_t>(std::strtoul(gm, nullptr, 0)) : 0xFFFFFFFFu;
+  }
   a.vertex_first    = g.vertex_first;
+  a.hub_items        = s.hub_items;
+  a.n_hub_items      = s.n_hub_items;
+  a.hub_item_partial = s.hub_item_partial.as<double>();
+  a.xs.block_begin   = s.xs_block_begin;
+  a.xs.n_blocks      = s.n_xs_blocks;
+  {
+    char const* am      = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
+    a.xs.affinity_mode = am ? std::atoi(am) : 0;
+  }
+  if (s.xs_on) {
+    PullPlan const& plan = *s.graph->plan;
+    a.xs.src       = plan.xs_src.as<int32_t>();
+    a.xs.rowl      = plan.xs_rowl.as<uint16_t>();
+    a.xs.w         = plan.xs_w.p ? plan.xs_w.as<ValT>() : nullptr;
+    a.xs.unit_off  = plan.xs_unit_off.as<int64_t>();
+    a.xs.tile_row  = plan.xs_tile_row.as<int32_t>();
+    a.xs.partial   = s.xs_partial.as<ValT>();
+    a.xs.counters  = s.xs_counters.as<int>();
+    a.xs.row_first = plan.xs_row_first;
+    a.xs.n_rows    = plan.xs_n_rows;
+    a.xs.n_tiles   = plan.xs_n_tiles;
+    CGA_HIP(hipMemsetAsync(s.xs_counters.p, 0, 256, stream));
+  }
   for (int b = 0; b < kNumBuckets; ++b) a.buckets[b] = s.buckets[b];
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
@@ -848,15 +1377,24 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   else
     hipLaunchKernelGGL((spmv_kernel<OffT, ValT, false>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
                        stream, a);
+  if (s.n_hub_blocks > 0)
+    hipLaunchKernelGGL((hub_finish_kernel<OffT, ValT>), dim3(s.n_hub_blocks), dim3(kThreads), 0,
+                       stream, a, s.hub_row_item_off, s.partials.as<double>() + 2 * s.n_spmv_blocks);
+  if (s.n_xs_finish_blocks > 0)
+    hipLaunchKernelGGL((xs_finish_kernel<OffT, ValT>), dim3(s.n_xs_finish_blocks), dim3(kThreads), 0,
+                       stream, a, s.partials.as<double>() + 2 * (s.n_spmv_blocks + s.n_hub_blocks));
   if (ev_kernel_end) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
   if (s.n_pers_blocks > 0)
     hipLaunchKernelGGL((pers_fix_kernel<ValT>), dim3(s.n_pers_blocks), dim3(kThreads), 0, stream,
                        s.pers_v.as<int32_t>(), s.pers_p.as<ValT>(), s.n_pers, a.pr_old, a.pr_new,
                        a.x_next, a.out_w, a.scal, a.ctrl, a.epsilon, a.alpha, a.one_minus_alpha,
-                       a.vertex_first, s.partials.as<double>() + 2 * s.n_spmv_blocks);
+                       a.vertex_first,
+                       s.partials.as<double>() +
+                         2 * (s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks));
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, stream, s.partials.as<double>(),
-                     s.n_spmv_blocks + s.n_pers_blocks, s.scal.as<double>(), s.ctrl.as<Ctrl>(),
-                     s.epsilon, 1);
+                     s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks + s.n_pers_blocks,
+                     s.scal.as<double>(),
+                     s.ctrl.as<Ctrl>(), s.epsilon, 1);
   CGA_HIP(hipGetLastError());
   s.enqueued += 1;
 }
@@ -1013,10 +1551,10 @@ void session_info(Session& s, int64_t info[8])
   int64_t boff = g.off64 ? 8 : 4;
   info[0]      = g.num_edges * (4 + bw) + (g.num_vertices + 1) * boff + 5 * g.num_vertices * bval;
   info[1]      = g.num_edges;
-  info[2]      = s.buckets[3].count + s.buckets[2].count;
-  info[3]      = s.buckets[1].count;
+  info[2]      = s.buckets[4].count + s.buckets[3].count + s.buckets[2].count;
+  info[3]      = s.xs_on ? s.graph->plan->xs_n_rows : s.buckets[1].count;
   info[4]      = s.buckets[0].count;
-  info[5]      = 0;
+  info[5]      = s.n_hub_items;
   info[6]      = s.n_spmv_blocks;
   info[7]      = s.enqueued;
 }

@@ -139,12 +139,15 @@ def test_rmat_generator_matches_oracle(scale, ef, scramble):
 @pytest.mark.parametrize("scale", [10, 14, 17])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_rmat_pagerank_vs_oracle(scale, dtype, weighted):
+@pytest.mark.parametrize("xs_tiles", [False, True])
+def test_rmat_pagerank_vs_oracle(scale, dtype, weighted, xs_tiles, monkeypatch):
     """R-MAT (hubs, multi-edges, self-loops, dangling and isolated vertices): CSC bit-exact, ranks
     within 1e-6 (fp32) / 1e-10 (fp64) max-abs of the C oracle, same iteration count."""
     import oracle
     from cugraph_amd import pylibcugraph as plc
 
+    # the XS tile path (mid-degree rows) is only chosen for big graphs unless forced
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0" if xs_tiles else str(1 << 40))
     nv, ne = 1 << scale, 16 << scale
     src, dst = oracle.rmat_edges(scale, ne, seed=42)
     wgt = oracle.rmat_weights(ne, seed=43).astype(dtype) if weighted else None
