@@ -43,12 +43,16 @@ constexpr int64_t kHubChunk = 32768;  // edges of one hub work item (longer colu
 
 // XS ("XCD-sliced, source-sorted") tiles for the mid-degree rows: see the comment at xs_bucket
 constexpr int kXsSlices       = 8;      // one slice of the source ids per XCD
-constexpr int64_t kXsTileEdges = 1 << 20;  // a tile is a run of rows holding about this many edges,
+constexpr int64_t kXsTileEdges = 1 << 22;  // a tile is a run of rows holding about this many edges,
 constexpr int kXsMaxRows      = 4096;     // but never more than this many rows (LDS accumulators)
-constexpr int kXsMinDegree    = 16;
+constexpr int kXsMinDegree    = 4;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
-__host__ __device__ inline uint32_t xs_slice_of(uint32_t src) { return (src >> 5) & (kXsSlices - 1); }
+// slice of a source id: interleaved in granules of 2^shift ids (default 32 ids = one 128-B line)
+__host__ __device__ inline uint32_t xs_slice_of(uint32_t src, int shift)
+{
+  return (src >> shift) & (kXsSlices - 1);
+}
 
 template <typename ValT>
 struct XsArgs {
@@ -305,9 +309,20 @@ __device__ inline void hub_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b
   }
 }
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+
+// streamed-once data (XS entries): non-temporal loads, so that they do not push the gathered
+// vector out of the XCD's L2
+__device__ inline int4 stream_load_i4(int32_t const* p)
+{
+  v4i_t v = __builtin_nontemporal_load(reinterpret_cast<v4i_t const*>(p));
+  return int4{v.x, v.y, v.z, v.w};
+}
+
 __device__ inline void load4u16(uint16_t const* p, uint32_t* r)
 {
-  uint2 v = *reinterpret_cast<uint2 const*>(p);
+  v2u_t v = __builtin_nontemporal_load(reinterpret_cast<v2u_t const*>(p));
   r[0] = v.x & 0xffffu; r[1] = v.x >> 16; r[2] = v.y & 0xffffu; r[3] = v.y >> 16;
 }
 
@@ -356,8 +371,8 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
       for (int64_t j = (beg & ~int64_t(3)) + (int64_t)tid * 4; j < end; j += 2 * kThreads * 4) {
         int64_t j2 = j + kThreads * 4;
         bool two   = j2 < end;
-        int4 q     = *reinterpret_cast<int4 const*>(xs.src + j);
-        int4 r     = two ? *reinterpret_cast<int4 const*>(xs.src + j2) : int4{0, 0, 0, 0};
+        int4 q     = stream_load_i4(xs.src + j);
+        int4 r     = two ? stream_load_i4(xs.src + j2) : int4{0, 0, 0, 0};
         uint32_t rl[8];
         load4u16(xs.rowl + j, rl);
         if (two) load4u16(xs.rowl + j2, rl + 4);
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT
 template <typename OffT>
 __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const* __restrict__ indices,
                                 int64_t row_first, int64_t n_rows, int64_t e0,
-                                int32_t const* __restrict__ tile_of_row,
+                                int32_t const* __restrict__ tile_of_row, int slice_shift,
                                 int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge)
 {
   constexpr int G = 16;
@@ -485,7 +500,7 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
     int64_t end = static_cast<int64_t>(offsets[row_first + i + 1]);
     int32_t t   = tile_of_row[i];
     for (int64_t j = beg + lane; j < end; j += G) {
-      unit[j - e0]        = t * kXsSlices + static_cast<int32_t>(xs_slice_of(static_cast<uint32_t>(indices[j])));
+      unit[j - e0]        = t * kXsSlices + static_cast<int32_t>(xs_slice_of(static_cast<uint32_t>(indices[j]), slice_shift));
       row_of_edge[j - e0] = static_cast<int32_t>(i);
     }
   }
@@ -497,12 +512,13 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
 // makes its tile longer.  flags mark the first row of each tile; a scan numbers the tiles.
 template <typename OffT>
 __global__ void xs_break_flags_kernel(OffT const* __restrict__ offsets, int64_t row_first,
-                                      int64_t n_rows, int64_t e0, unsigned int* __restrict__ flags)
+                                      int64_t n_rows, int64_t e0, int64_t tile_edges,
+                                      unsigned int* __restrict__ flags)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t w  = (static_cast<int64_t>(offsets[row_first + i]) - e0) / kXsTileEdges;
-    int64_t wp = i == 0 ? -1 : (static_cast<int64_t>(offsets[row_first + i - 1]) - e0) / kXsTileEdges;
+    int64_t w  = (static_cast<int64_t>(offsets[row_first + i]) - e0) / tile_edges;
+    int64_t wp = i == 0 ? -1 : (static_cast<int64_t>(offsets[row_first + i - 1]) - e0) / tile_edges;
     flags[i]   = (w != wp || (i % kXsMaxRows) == 0) ? 1u : 0u;
   }
 }
@@ -919,10 +935,14 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   char const* min_env = std::getenv("CUGRAPH_AMD_XS_MIN_EDGES");
   int64_t min_edges   = min_env ? std::atoll(min_env) : (int64_t(1) << 22);
   if (ne < min_edges || ne == 0 || ne > 0xffffffffLL) return;
+  char const* te_env  = std::getenv("CUGRAPH_AMD_XS_TILE_EDGES");
+  int64_t tile_edges  = te_env ? std::atoll(te_env) : kXsTileEdges;
+  char const* sh_env  = std::getenv("CUGRAPH_AMD_XS_SLICE_SHIFT");
+  int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
-                     offsets, row_first, n_rows, e0, flags.as<unsigned int>());
+                     offsets, row_first, n_rows, e0, tile_edges, flags.as<unsigned int>());
   exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n_rows, pos.as<int64_t>());
   int64_t n_tiles64 = 0;
   CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
@@ -938,7 +958,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
 
   DevBuf unit(static_cast<size_t>(ne) * 4), row_of_edge(static_cast<size_t>(ne) * 4);
   hipLaunchKernelGGL((xs_label_kernel<OffT>), dim3(grid_for(n_rows * 16)), dim3(kThreads), 0, stream,
-                     offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(),
+                     offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(), slice_shift,
                      unit.as<int32_t>(), row_of_edge.as<int32_t>());
   CGA_HIP(hipGetLastError());
   CompressedOut c = compress_coo_perm(stream, n_units, g.num_global_vertices, ne, unit.as<int32_t>(),
