@@ -71,6 +71,10 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # libraries (RCCL's banner, ...) write to the C-level stdout: keep fd 1 for the one JSON line
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,7 +231,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -161,6 +161,10 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
   g->offsets = out.offsets.detach();
   g->indices = static_cast<int32_t*>(out.indices.detach());
   g->weights = out.weights.p ? out.weights.detach() : nullptr;
+  // majors that already come in descending degree order (renumber=TRUE, or a partition the
+  // multi-GPU driver relabelled) run on contiguous degree buckets without a sorted copy
+  if (store_transposed && !g->degree_sorted)
+    g->degree_sorted = degrees_descending(stream, g->offsets, g->off64, g->num_vertices);
   return g.release();
 }
 
@@ -571,6 +575,29 @@ cugraph_error_code_t cugraph_amd_graph_create_local(
                           as<ArrayView>(dst), as<ArrayView>(weights), true, false, false, false,
                           vertex_first, vertex_last, num_global_vertices);
     *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_partition_degree_order(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* dst,
+  int64_t vertex_first, int64_t vertex_last, cugraph_type_erased_device_array_view_t* order,
+  cugraph_type_erased_device_array_view_t* rank, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto const* d = as<ArrayView>(dst);
+    auto* o       = as<ArrayView>(order);
+    auto* r       = as<ArrayView>(rank);
+    CGA_EXPECTS(d && o && r, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(is_int_type(d->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "dst must be INT32 or INT64");
+    int64_t n = vertex_last - vertex_first;
+    CGA_EXPECTS(vertex_first >= 0 && n >= 0 && n < 0x7fffffffLL, CUGRAPH_INVALID_INPUT,
+                "invalid local vertex range");
+    CGA_EXPECTS(o->type == INT32 && r->type == INT32 && static_cast<int64_t>(o->size) == n &&
+                  static_cast<int64_t>(r->size) == n,
+                CUGRAPH_INVALID_INPUT, "order / rank must be INT32 views of vertex_last - vertex_first elements");
+    partition_degree_order(as<Handle>(handle)->stream, *d, vertex_first, n,
+                           static_cast<int32_t*>(o->data), static_cast<int32_t*>(r->data));
   });
 }
 

@@ -229,6 +229,10 @@ Graph* degree_sorted_copy(Handle const& h, Graph const& g);
 void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
                        ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32);
 
+void partition_degree_order(hipStream_t stream, ArrayView const& dst, int64_t first, int64_t count,
+                            int32_t* order_out, int32_t* rank_out);
+bool degrees_descending(hipStream_t stream, void const* offsets, bool off64, int64_t n);
+
 // out[i] = in[i] - shift  /  out[i] = (int64) in[i]
 void shift_ids(hipStream_t stream, int32_t const* in, int32_t* out, int64_t n, int64_t shift);
 void widen_ids(hipStream_t stream, int32_t const* in, int64_t* out, int64_t n);

@@ -67,6 +67,7 @@ struct XsArgs {
   int n_tiles;
   int block_begin, n_blocks;
   int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
+  int dedupe;
 };
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
@@ -390,8 +391,16 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
           p[e]     = (j + e >= beg) && (j + e < end);
           p[4 + e] = two && (j2 + e < end);
         }
+        // entries are sorted by source: a lane's 4 consecutive entries often name the same one
+        bool need[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = p[e] ? a.x_cur[gi[e] & a.gather_mask] : ValT(0);
+        for (int e = 0; e < 8; ++e)
+          need[e] = p[e] && ((e & 3) == 0 || !xs.dedupe || gi[e] != gi[e - 1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = need[e] ? a.x_cur[gi[e] & a.gather_mask] : ValT(0);
+#pragma unroll
+        for (int e = 1; e < 8; ++e)
+          if ((e & 3) != 0) xv[e] = (p[e] && !need[e]) ? xv[e - 1] : xv[e];
         if constexpr (WEIGHTED) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] *= w[e];
@@ -1012,8 +1021,7 @@ PullPlan& get_plan(Handle const& h, Graph& g)
       else
         build_plan_lists<int32_t>(stream, cg, *p);
       char const* xs_env = std::getenv("CUGRAPH_AMD_XS");
-      bool want_xs = !(xs_env && xs_env[0] == '0') && p->contiguous &&
-                     cg.num_global_vertices == cg.num_vertices;
+      bool want_xs = !(xs_env && xs_env[0] == '0') && p->contiguous;
       if (want_xs) {
         bool f64 = cg.weight_type == FLOAT64;
         if (cg.off64) {
@@ -1373,6 +1381,8 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   {
     char const* am      = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
     a.xs.affinity_mode = am ? std::atoi(am) : 0;
+    char const* dd      = std::getenv("CUGRAPH_AMD_XS_DEDUPE");
+    a.xs.dedupe         = dd ? std::atoi(dd) : 1;
   }
   if (s.xs_on) {
     PullPlan const& plan = *s.graph->plan;

@@ -203,6 +203,83 @@ void relabel_ids(hipStream_t stream, int32_t* ids, int64_t n, int32_t const* tab
   CGA_HIP(hipGetLastError());
 }
 
+namespace {
+template <typename IdT>
+__global__ void local_hist_kernel(IdT const* ids, int64_t n, long long first, long long count,
+                                  unsigned int* counts, unsigned int* n_bad)
+{
+  GRID_STRIDE(i, n)
+  {
+    long long k = (long long)ids[i] - first;
+    if (k < 0 || k >= count)
+      atomicAdd(n_bad, 1u);
+    else
+      atomicAdd(&counts[k], 1u);
+  }
+}
+
+template <typename OffT>
+__global__ void degree_descending_kernel(OffT const* offsets, int64_t n, unsigned int* n_up)
+{
+  GRID_STRIDE(i, n - 1)
+  {
+    if (offsets[i + 2] - offsets[i + 1] > offsets[i + 1] - offsets[i]) atomicAdd(n_up, 1u);
+  }
+}
+}  // namespace
+
+// in-degree order of the destinations [first, first + count) a rank owns, from the destination
+// ids of its edges: order[new] = old - first, rank[old - first] = new (stable, descending)
+void partition_degree_order(hipStream_t stream, ArrayView const& dst, int64_t first, int64_t count,
+                            int32_t* order_out, int32_t* rank_out)
+{
+  size_t nn = static_cast<size_t>(count > 0 ? count : 1);
+  DevBuf deg(nn * 4), bad(4);
+  CGA_HIP(hipMemsetAsync(deg.p, 0, deg.bytes, stream));
+  CGA_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+  int64_t ne = static_cast<int64_t>(dst.size);
+  if (ne > 0) {
+    if (dst.type == INT64)
+      hipLaunchKernelGGL((local_hist_kernel<int64_t>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(dst.data), ne, first, count,
+                         deg.as<unsigned int>(), bad.as<unsigned int>());
+    else
+      hipLaunchKernelGGL((local_hist_kernel<int32_t>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(dst.data), ne, first, count,
+                         deg.as<unsigned int>(), bad.as<unsigned int>());
+    CGA_HIP(hipGetLastError());
+  }
+  unsigned int h_bad = 0;
+  CGA_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  CGA_EXPECTS(h_bad == 0, CUGRAPH_INVALID_INPUT, "destination ids outside this rank's vertex range");
+  if (count == 0) return;
+  DevBuf order, rank;
+  degree_order(stream, deg.as<unsigned int>(), count, order, rank);
+  CGA_HIP(hipMemcpyAsync(order_out, order.p, nn * 4, hipMemcpyDeviceToDevice, stream));
+  CGA_HIP(hipMemcpyAsync(rank_out, rank.p, nn * 4, hipMemcpyDeviceToDevice, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+}
+
+// true when the majors of a compressed graph are in non-increasing degree order
+bool degrees_descending(hipStream_t stream, void const* offsets, bool off64, int64_t n)
+{
+  if (n < 2) return true;
+  DevBuf up(4);
+  CGA_HIP(hipMemsetAsync(up.p, 0, 4, stream));
+  if (off64)
+    hipLaunchKernelGGL((degree_descending_kernel<int64_t>), dim3(grid_for(n, 2048)), dim3(kThreads), 0,
+                       stream, static_cast<int64_t const*>(offsets), n, up.as<unsigned int>());
+  else
+    hipLaunchKernelGGL((degree_descending_kernel<int32_t>), dim3(grid_for(n, 2048)), dim3(kThreads), 0,
+                       stream, static_cast<int32_t const*>(offsets), n, up.as<unsigned int>());
+  CGA_HIP(hipGetLastError());
+  unsigned int h_up = 1;
+  CGA_HIP(hipMemcpyAsync(&h_up, up.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  return h_up == 0;
+}
+
 // A degree-sorted copy of a compressed graph whose ids are 0..V-1 (the pull plan of graphs built
 // with renumber=FALSE).  number_map (int32) and ext_lookup describe the permutation.
 Graph* degree_sorted_copy(Handle const& h, Graph const& g)

@@ -22,6 +22,12 @@ SURVEY.md section 2.3:
 
 Rank r owns destinations [r*chunk, min((r+1)*chunk, V)) with chunk = ceil(V / P).
 
+Inside its range every rank relabels its vertices by descending in-degree (the reference renumbers
+by degree inside each partition too, renumber_edgelist_impl.cuh); the ranks all-gather the
+old -> new table once and relabel their sources with it.  Ownership does not change, so the
+collectives stay what they were, and the local SpMV runs on contiguous degree buckets and XS
+tiles exactly like the single-GPU path.  Callers keep seeing the ids they passed in.
+
 The local compute is reached through an *engine* object so that the driver logic (partition,
 routing, collectives, stop rule, result assembly) can be exercised at world_size 2 on CPU with
 a test double; the product engine is `HipEngine` and there is no other in this package.
@@ -87,6 +93,30 @@ class HipEngine:
         self.props = graph_properties
         self.device = "cuda"
 
+    def degree_order(self, dst, first, last):
+        """(order, rank) int32 tensors of the local destinations, descending in-degree."""
+        import ctypes
+
+        import torch
+
+        from . import _capi
+        from .pylibcugraph.utils import create_view_from_py_obj, free_view
+
+        n = last - first
+        order = torch.empty(n, dtype=torch.int32, device="cuda")
+        rank = torch.empty(n, dtype=torch.int32, device="cuda")
+        views = [create_view_from_py_obj(t) for t in (dst.contiguous(), order, rank)]
+        err = ctypes.c_void_p()
+        try:
+            code = _capi.load().cugraph_amd_partition_degree_order(
+                self.handle.c_resource_handle_ptr, views[0], first, last, views[1], views[2],
+                ctypes.byref(err))
+            _capi.check(code, err, "cugraph_amd_partition_degree_order")
+        finally:
+            for v in views:
+                free_view(v)
+        return order, rank
+
     def make_local_graph(self, src, dst, wgt, first, last, num_global):
         from . import pylibcugraph as plc
 
@@ -133,7 +163,9 @@ class MGPagerank:
         self.rank, self.world, self.group = rank, world, group
         self.first, self.last, self.chunk = partition_bounds(self.num_vertices, world, rank)
         self.graph = None
-        self.out_w = None  # out-weight sums of the local vertices (float64)
+        self.order = None  # int32[n_local]: internal position -> offset of the caller's id in the range
+        self.new_id = None  # [chunk * world]: caller's id -> internal id, every rank's range
+        self.out_w = None  # out-weight sums of the local vertices (float64), internal order
         self.value_dtype = None
         self.vertex_dtype = None
         self.t_generate = 0.0
@@ -155,6 +187,15 @@ class MGPagerank:
         self.value_dtype = torch.float32 if wgt is None else wgt.dtype
         if world > 1:
             src, dst, wgt = shuffle_edges_to_owner(src, dst, wgt, self.chunk, world, group)
+        # descending in-degree inside the owned range; one all-gather of the old -> new table
+        self.order, rank_local = engine.degree_order(dst, self.first, self.last)
+        self.new_id = torch.zeros(self.chunk * world, dtype=src.dtype, device=src.device)
+        self.new_id[self.first:self.last] = rank_local.to(src.dtype) + self.first
+        del rank_local
+        if world > 1:
+            all_gather_in_place(self.new_id, self.chunk, rank, world, group)
+        src = self.new_id[src.long()] if src.dtype != torch.int32 else self.new_id[src]
+        dst = self.new_id[dst.long()] if dst.dtype != torch.int32 else self.new_id[dst]
         self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last,
                                              self.num_vertices)
         del src, dst, wgt
@@ -198,7 +239,8 @@ class MGPagerank:
         v = torch.as_tensor(vertices, device=self.engine.device).to(self.vertex_dtype)
         x = torch.as_tensor(values, device=self.engine.device).to(torch.float64)
         keep = (v >= self.first) & (v < self.last)
-        return v[keep].contiguous(), (x[keep] / scale).to(self.value_dtype).contiguous()
+        v = self.new_id[v[keep].long()].to(self.vertex_dtype)
+        return v.contiguous(), (x[keep] / scale).to(self.value_dtype).contiguous()
 
     def session(self, *, alpha=0.85, epsilon=1e-6, nstart=None, personalization=None):
         """nstart / personalization: optional (vertices, values) pairs, the SAME on every rank.
@@ -263,8 +305,14 @@ class MGPagerank:
 
     def result(self, sess, max_iterations):
         """(local vertex ids, local ranks, iterations, converged) -- per-rank slices, as the
-        reference returns per worker (dask/link_analysis/pagerank.py:426-427)."""
-        return sess.inner.result(max_iterations)
+        reference returns per worker (dask/link_analysis/pagerank.py:426-427); ids are the
+        caller's, ascending."""
+        import torch
+
+        verts, vals, iters, conv = sess.inner.result(max_iterations)
+        out = torch.empty_like(vals)
+        out[self.order.long()] = vals  # internal position -> the caller's id order
+        return verts, out, iters, conv
 
     def gathered_result(self, sess, max_iterations):
         """Every rank gets the full rank vector (tests / small graphs)."""

@@ -251,6 +251,18 @@ cugraph_error_code_t cugraph_amd_graph_create_local(
   int64_t vertex_last, int64_t num_global_vertices, cugraph_graph_t** graph,
   cugraph_error_t** error);
 
+/* Descending in-degree order of the destinations [vertex_first, vertex_last) a rank owns, from
+ * the destination ids (INT32/INT64, global) of the edges routed to it:
+ *   order[new] = old - vertex_first,  rank[old - vertex_first] = new   (INT32 views, stable).
+ * The multi-GPU driver relabels every partition with it (ids stay inside their owner's range), so
+ * that the local SpMV runs on contiguous degree buckets and XS tiles like the single-GPU path
+ * (the reference renumbers by degree inside each partition too: renumber_edgelist,
+ * cpp/src/structure/renumber_edgelist_impl.cuh, compute_renumber_map). */
+cugraph_error_code_t cugraph_amd_partition_degree_order(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* dst,
+  int64_t vertex_first, int64_t vertex_last, cugraph_type_erased_device_array_view_t* order,
+  cugraph_type_erased_device_array_view_t* rank, cugraph_error_t** error);
+
 /* Shape of a graph: info[0]=num_vertices (local majors), [1]=num_edges, [2]=num_global_vertices,
  * [3]=vertex_first, [4]=store_transposed, [5]=offsets are int64, [6]=weighted, [7]=renumbered */
 cugraph_error_code_t cugraph_amd_graph_info(const cugraph_graph_t* graph, int64_t info[8],

@@ -89,6 +89,13 @@ class OracleEngine:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
 
+    def degree_order(self, dst, first, last):
+        deg = np.bincount(dst.numpy().astype(np.int64) - first, minlength=last - first)
+        order = np.argsort(-deg, kind="stable").astype(np.int32)
+        rank = np.empty_like(order)
+        rank[order] = np.arange(len(order), dtype=np.int32)
+        return torch.from_numpy(order), torch.from_numpy(rank)
+
     def make_local_graph(self, src, dst, wgt, first, last, num_global):
         return _Graph(src, dst, wgt, first, last, num_global)
 

@@ -268,10 +268,95 @@ def test_nstart_and_precomputed_out_weights(relabel, monkeypatch):
     assert np.max(np.abs(r.cpu().numpy() - o_pr)) <= 1e-6
 
 
-def test_mg_driver_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("xs_tiles", [False, True])
+def test_partitioned_sessions_emulated_ranks(world, weighted, xs_tiles, monkeypatch):
+    """The HIP side of the multi-GPU path for every rank of a 2- and 3-way partition, all run in
+    this one process: per-rank degree relabel (cugraph_amd_partition_degree_order), local graph
+    with vertex_first != 0, XS tiles on a partition, and the exchange buffers; the all-gather and
+    the scalar all-reduce are done by hand between the sessions.  (The collectives themselves are
+    covered by tests/test_mg_cpu.py over gloo and by test_mg_driver_on_one_gpu over RCCL.)"""
+    import torch
+    import oracle
+    from cugraph_amd import mg, pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0" if xs_tiles else str(1 << 40))
+    scale = 12
+    nv, ne = (1 << scale) - 5, 16 << scale  # V not a multiple of the world size
+    src, dst = oracle.rmat_edges(scale, ne, seed=11, scramble=True)
+    keep = (src < nv) & (dst < nv)
+    src, dst = src[keep], dst[keep]
+    wgt = oracle.rmat_weights(len(src), seed=12).astype(np.float32) if weighted else None
+    props = plc.GraphProperties(is_multigraph=True)
+    chunk = (nv + world - 1) // world
+    engines, orders, ranks_l, bounds = [], [], [], []
+    new_id = torch.zeros(chunk * world, dtype=torch.int32, device="cuda")
+    for r in range(world):
+        first, last, _ = mg.partition_bounds(nv, world, r)
+        eng = mg.HipEngine(plc.ResourceHandle(rank=r, comm_size=world), props)
+        sel = (dst >= first) & (dst < last)
+        order, rank_l = eng.degree_order(to_dev(dst[sel]), first, last)
+        deg = np.bincount(dst[sel] - first, minlength=last - first)
+        assert np.array_equal(order.cpu().numpy(), np.argsort(-deg, kind="stable"))
+        new_id[first:last] = rank_l + first
+        engines.append(eng), orders.append(order), bounds.append((first, last, sel))
+    graphs, sums = [], torch.zeros(nv, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        first, last, sel = bounds[r]
+        g = engines[r].make_local_graph(new_id[to_dev(src[sel]).long()], new_id[to_dev(dst[sel]).long()],
+                                        None if wgt is None else to_dev(wgt[sel]), first, last, nv)
+        sums += engines[r].source_weight_sums(g, nv)
+        graphs.append(g)
+    eps = nv * 1e-8
+    sessions = []
+    for r in range(world):
+        first, last, _ = bounds[r]
+        ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
+        sessions.append(engines[r].make_session(
+            graphs[r], alpha=0.85, epsilon=eps, precomputed_vertex_out_weight_vertices=ids,
+            precomputed_vertex_out_weight_sums=sums[first:last].to(torch.float32)))
+
+    def exchange():
+        bufs = [s.exchange_buffers() for s in sessions]
+        x = torch.zeros_like(bufs[0][0])
+        scal = torch.zeros(2, dtype=torch.float64, device="cuda")
+        for r, (xf, sc) in enumerate(bufs):
+            first, last, _ = bounds[r]
+            x[first:last] = xf[first:last]
+            scal += sc
+        for xf, sc in bufs:
+            xf.copy_(x), sc.copy_(scal)
+
+    exchange()
+    for _ in range(500):
+        for s in sessions:
+            s.iterate(1)
+        exchange()
+        st = [s.status() for s in sessions]
+        assert len({(a[0], a[1]) for a in st}) == 1  # every rank agrees on iteration and stop
+        if st[0][1]:
+            break
+    full = np.zeros(nv)
+    for r, s in enumerate(sessions):
+        first, last, _ = bounds[r]
+        verts, vals, iters, conv = s.result(500)
+        assert np.array_equal(verts.cpu().numpy(), np.arange(first, last))
+        full[first + orders[r].cpu().numpy()] = vals.cpu().numpy()
+    off, idx, perm = oracle.compress(nv, dst, src)
+    o_pr, o_it, _ = oracle.pagerank(nv, off, idx, None if wgt is None else wgt[perm], dtype=np.float64,
+                                    alpha=0.85, epsilon=eps, max_iterations=500)
+    assert iters == o_it and conv
+    assert np.max(np.abs(full - o_pr)) <= 1e-6
+
+
+@pytest.mark.parametrize("xs_tiles", [False, True])
+def test_mg_driver_on_one_gpu(xs_tiles, monkeypatch):
     """The multi-GPU driver with its HIP engine and RCCL collectives, one rank: 1D-partitioned
-    local graph, out-weight all-reduce, in-place all-gather of x, 2-scalar all-reduce."""
+    local graph, out-weight all-reduce, in-place all-gather of x, 2-scalar all-reduce; nstart and
+    personalization in the caller's ids."""
     import os
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0" if xs_tiles else str(1 << 40))
     import torch
     import torch.distributed as dist
     import oracle
@@ -298,6 +383,23 @@ def test_mg_driver_on_one_gpu():
         o_pr, o_it, _ = oracle.pagerank(nv, off, idx, None, dtype=np.float64, alpha=0.85,
                                         epsilon=eps, max_iterations=500)
         assert stopped and conv and iters == o_it == it2
+        assert np.max(np.abs(full.cpu().numpy() - o_pr)) <= 1e-6
+        verts, vals, _, _ = drv.result(sess, 500)
+        assert np.array_equal(verts.cpu().numpy(), np.arange(nv))
+        assert np.array_equal(vals.cpu().numpy(), full.cpu().numpy())
+        # personalization (un-normalised) and a partial initial guess, ids as the caller knows them
+        rng = np.random.default_rng(5)
+        pers = (rng.permutation(nv)[:50].astype(np.int32), (rng.random(50) + 0.1).astype(np.float32))
+        nstart = (rng.permutation(nv)[:3000].astype(np.int32), (rng.random(3000) / 1500).astype(np.float32))
+        sess = drv.session(alpha=0.85, epsilon=1e-30, nstart=nstart, personalization=pers)
+        drv.run_to_convergence(sess, 5, check_every=2)
+        full, it2, conv = drv.gathered_result(sess, 5)
+        ns = np.zeros(nv)
+        ns[nstart[0]] = nstart[1]
+        o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, None, dtype=np.float64, alpha=0.85,
+                                             epsilon=1e-30, max_iterations=5, nstart=ns,
+                                             pers_vertices=pers[0], pers_values=pers[1])
+        assert it2 == o_it == 5 and not conv and not o_conv
         assert np.max(np.abs(full.cpu().numpy() - o_pr)) <= 1e-6
     finally:
         if own:
