@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -48,18 +49,33 @@ constexpr int kXsMaxRows      = 4096;     // but never more than this many rows 
 constexpr int kXsMinDegree    = 4;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
-// slice of a source id: interleaved in granules of 2^shift ids (default 32 ids = one 128-B line)
+constexpr int kXsRowBits      = 12;       // log2(kXsMaxRows): row field of a packed entry
+constexpr int kXsLowBits      = 32 - kXsRowBits;  // source bits an entry carries; the rest is its window
+
+// slice of a source id: interleaved in granules of 2^shift ids (default 128 ids = four 128-B lines)
 __host__ __device__ inline uint32_t xs_slice_of(uint32_t src, int shift)
 {
   return (src >> shift) & (kXsSlices - 1);
 }
+// position of a source inside its slice (the slice bits squeezed out) and back
+__host__ __device__ inline uint32_t xs_slice_local(uint32_t src, int shift)
+{
+  return ((src >> (shift + 3)) << shift) | (src & ((1u << shift) - 1u));
+}
+__host__ __device__ inline uint32_t xs_global_id(uint32_t local, uint32_t slice, int shift)
+{
+  return ((local >> shift) << (shift + 3)) | (slice << shift) | (local & ((1u << shift) - 1u));
+}
 
 template <typename ValT>
 struct XsArgs {
-  int32_t const* src;        // [n_edges + 4] sources, ascending inside each (tile, slice) unit
-  uint16_t const* rowl;      // [n_edges + 4] row of the entry, relative to its tile's first row
+  // packed entries [n_edges + 4], ascending source inside each (tile, slice, window) unit:
+  // (low 20 bits of the source's slice-local position) << 12 | row relative to the tile's first
+  uint32_t const* ent;
   ValT const* w;             // [n_edges + 4] or nullptr
-  int64_t const* unit_off;   // [n_tiles * 8 + 1]
+  int64_t const* unit_off;   // [n_tiles * 8 * n_win + 1]
+  int n_win;                 // windows of 2^20 slice-local positions per slice
+  int slice_shift;
   int32_t const* tile_row;   // [n_tiles + 1] first row of each tile, relative to row_first
   ValT* partial;             // [8][n_rows] per-slice partial sums
   int* counters;             // [8] next tile of each slice's queue
@@ -157,8 +173,8 @@ struct Epilogue {
   {
     ValT pr = base + a.alpha * weighted_sum;
     if (a.pers_dense) pr += teleport * a.pers_dense[v];
-    ValT old = a.pr_old[v];
-    ValT ow  = a.out_w[v];
+    ValT old = __builtin_nontemporal_load(a.pr_old + v);
+    ValT ow  = __builtin_nontemporal_load(a.out_w + v);
     delta += fabs(static_cast<double>(pr) - static_cast<double>(old));
     ValT x = pr;
     if (ow == ValT(0)) {
@@ -166,8 +182,8 @@ struct Epilogue {
     } else {
       x = pr / ow;
     }
-    a.pr_new[v]                 = pr;
-    a.x_next[a.vertex_first + v] = x;
+    __builtin_nontemporal_store(pr, a.pr_new + v);
+    __builtin_nontemporal_store(x, a.x_next + a.vertex_first + v);
   }
 };
 
@@ -315,16 +331,10 @@ typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
 
 // streamed-once data (XS entries): non-temporal loads, so that they do not push the gathered
 // vector out of the XCD's L2
-__device__ inline int4 stream_load_i4(int32_t const* p)
+__device__ inline void stream_load4(uint32_t const* p, uint32_t* r)
 {
   v4i_t v = __builtin_nontemporal_load(reinterpret_cast<v4i_t const*>(p));
-  return int4{v.x, v.y, v.z, v.w};
-}
-
-__device__ inline void load4u16(uint16_t const* p, uint32_t* r)
-{
-  v2u_t v = __builtin_nontemporal_load(reinterpret_cast<v2u_t const*>(p));
-  r[0] = v.x & 0xffffu; r[1] = v.x >> 16; r[2] = v.y & 0xffffu; r[3] = v.y >> 16;
+  r[0] = (uint32_t)v.x; r[1] = (uint32_t)v.y; r[2] = (uint32_t)v.z; r[3] = (uint32_t)v.w;
 }
 
 // XS tiles.  The gathers of a pull SpMV are bound by two request rates, not by bytes: ~240 G/s
@@ -363,44 +373,61 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
       int const rows = xs.tile_row[t + 1] - row0;
       for (int i = tid; i < rows; i += kThreads) acc[i] = 0;
       __syncthreads();
-      int64_t const beg = xs.unit_off[(int64_t)t * kXsSlices + k];
-      int64_t const end = xs.unit_off[(int64_t)t * kXsSlices + k + 1];
       // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
       // so every lane keeps the 4 row sums in registers and the block reduces them at the end
       bool const few = rows <= 4;
       double racc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int64_t j = (beg & ~int64_t(3)) + (int64_t)tid * 4; j < end; j += 2 * kThreads * 4) {
-        int64_t j2 = j + kThreads * 4;
-        bool two   = j2 < end;
-        int4 q     = stream_load_i4(xs.src + j);
-        int4 r     = two ? stream_load_i4(xs.src + j2) : int4{0, 0, 0, 0};
-        uint32_t rl[8];
-        load4u16(xs.rowl + j, rl);
-        if (two) load4u16(xs.rowl + j2, rl + 4);
+      int const shift = xs.slice_shift;
+      // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
+      // from its position (boundaries relative to the aligned start; up to 8 kept in registers)
+      int64_t const u0    = ((int64_t)t * kXsSlices + k) * xs.n_win;
+      int64_t const beg   = xs.unit_off[u0];
+      int64_t const end   = xs.unit_off[u0 + xs.n_win];
+      int64_t const abeg  = beg & ~int64_t(3);
+      uint32_t const rbeg = static_cast<uint32_t>(beg - abeg);
+      uint32_t const rend = static_cast<uint32_t>(end - abeg);
+      uint32_t wb[8];
+#pragma unroll
+      for (int w = 1; w < 8; ++w)
+        wb[w] = w < xs.n_win ? static_cast<uint32_t>(xs.unit_off[u0 + w] - abeg) : 0xFFFFFFFFu;
+      auto window_of = [&](uint32_t pos) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 1; w < 8; ++w) c += pos >= wb[w] ? 1u : 0u;
+        for (int w = 8; w < xs.n_win; ++w)  // more than 2^26 vertices per slice
+          c += pos >= static_cast<uint32_t>(xs.unit_off[u0 + w] - abeg) ? 1u : 0u;
+        return c;
+      };
+      uint32_t const low_mask = (1u << shift) - 1u;
+      // one pass of the workgroup over 2048 entries (8 per lane).  FAST: all of them exist and
+      // lie in one window (decided on uniform values), so no per-entry predicates or windows.
+      auto pass = [&](auto fast_tag, uint32_t pb, uint32_t win_uniform) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        // entry e of lane tid: pb + e * 256 + tid, so that the 64 lanes of one gather instruction
+        // hold 64 CONSECUTIVE entries (ascending sources: few cache lines per instruction)
+        uint32_t const pos = pb + static_cast<uint32_t>(tid);
+        uint32_t en[8];
         ValT w[8];
-        if constexpr (WEIGHTED) {
-          load4(xs.w + j, w);
-          if (two) load4(xs.w + j2, w + 4);
-        }
-        uint32_t gi[8] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w,
-                          (uint32_t)r.x, (uint32_t)r.y, (uint32_t)r.z, (uint32_t)r.w};
         bool p[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          uint32_t q = pos + e * kThreads;
+          p[e]       = FAST || (q >= rbeg && q < rend);
+          en[e]      = p[e] ? __builtin_nontemporal_load(xs.ent + abeg + q) : 0u;
+          if constexpr (WEIGHTED) w[e] = p[e] ? __builtin_nontemporal_load(xs.w + abeg + q) : ValT(0);
+        }
+        uint32_t loc[8];  // slice-local source position
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          uint32_t wn = FAST ? win_uniform : window_of(pos + e * kThreads);
+          loc[e]      = (wn << kXsLowBits) | (en[e] >> kXsRowBits);
+        }
         ValT xv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          p[e]     = (j + e >= beg) && (j + e < end);
-          p[4 + e] = two && (j2 + e < end);
+        for (int e = 0; e < 8; ++e) {
+          uint32_t gi = ((loc[e] & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc[e] & low_mask);
+          xv[e]       = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
         }
-        // entries are sorted by source: a lane's 4 consecutive entries often name the same one
-        bool need[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          need[e] = p[e] && ((e & 3) == 0 || !xs.dedupe || gi[e] != gi[e - 1]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = need[e] ? a.x_cur[gi[e] & a.gather_mask] : ValT(0);
-#pragma unroll
-        for (int e = 1; e < 8; ++e)
-          if ((e & 3) != 0) xv[e] = (p[e] && !need[e]) ? xv[e - 1] : xv[e];
         if constexpr (WEIGHTED) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[e] *= w[e];
@@ -408,15 +435,23 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
         if (few) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            double v = p[e] ? static_cast<double>(xv[e]) : 0.0;
+            double v    = p[e] ? static_cast<double>(xv[e]) : 0.0;
+            uint32_t rl = en[e] & (kXsMaxRows - 1);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) racc[rr] += rl[e] == (uint32_t)rr ? v : 0.0;
+            for (int rr = 0; rr < 4; ++rr) racc[rr] += rl == (uint32_t)rr ? v : 0.0;
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            if (p[e]) atomicAdd(&acc[rl[e]], static_cast<XsAcc>(xv[e]));
+            if (p[e]) atomicAdd(&acc[en[e] & (kXsMaxRows - 1)], static_cast<XsAcc>(xv[e]));
         }
+      };
+      for (uint32_t pb = 0; pb < rend; pb += 2 * kThreads * 4) {
+        uint32_t const w_lo = window_of(pb), w_hi = window_of(pb + 2 * kThreads * 4 - 1);
+        if (pb >= rbeg && pb + 2 * kThreads * 4 <= rend && w_lo == w_hi)
+          pass(std::true_type{}, pb, w_lo);
+        else
+          pass(std::false_type{}, pb, 0u);
       }
       if (few) {
 #pragma unroll
@@ -427,7 +462,8 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
       }
       __syncthreads();
       ValT* out = xs.partial + (int64_t)k * xs.n_rows + row0;
-      for (int i = tid; i < rows; i += kThreads) out[i] = static_cast<ValT>(acc[i]);
+      for (int i = tid; i < rows; i += kThreads)
+        __builtin_nontemporal_store(static_cast<ValT>(acc[i]), out + i);
       __syncthreads();
     }
   }
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT
 template <typename OffT>
 __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const* __restrict__ indices,
                                 int64_t row_first, int64_t n_rows, int64_t e0,
-                                int32_t const* __restrict__ tile_of_row, int slice_shift,
+                                int32_t const* __restrict__ tile_of_row, int slice_shift, int n_win,
                                 int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge)
 {
   constexpr int G = 16;
@@ -509,7 +545,10 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
     int64_t end = static_cast<int64_t>(offsets[row_first + i + 1]);
     int32_t t   = tile_of_row[i];
     for (int64_t j = beg + lane; j < end; j += G) {
-      unit[j - e0]        = t * kXsSlices + static_cast<int32_t>(xs_slice_of(static_cast<uint32_t>(indices[j]), slice_shift));
+      uint32_t src   = static_cast<uint32_t>(indices[j]);
+      uint32_t slice = xs_slice_of(src, slice_shift);
+      uint32_t win   = xs_slice_local(src, slice_shift) >> kXsLowBits;
+      unit[j - e0]   = (t * kXsSlices + static_cast<int32_t>(slice)) * n_win + static_cast<int32_t>(win);
       row_of_edge[j - e0] = static_cast<int32_t>(i);
     }
   }
@@ -554,19 +593,41 @@ __global__ void xs_payload_kernel(int32_t const* __restrict__ tile_of_row, int64
                                   int32_t const* __restrict__ row_of_edge,
                                   int32_t const* __restrict__ tile_row,
                                   ValT const* __restrict__ w_in, UOffT const* __restrict__ unit_off_in,
-                                  int64_t n_units, uint16_t* __restrict__ rowl,
+                                  int64_t n_units, int32_t const* __restrict__ src_sorted,
+                                  int slice_shift, uint32_t* __restrict__ ent,
                                   ValT* __restrict__ w_out, int64_t* __restrict__ unit_off_out)
 {
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_edges;
        k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t e = perm[k];
     int32_t r  = row_of_edge[e];
-    rowl[k]    = static_cast<uint16_t>(r - tile_row[tile_of_row[r]]);
+    uint32_t rl  = static_cast<uint32_t>(r - tile_row[tile_of_row[r]]);
+    uint32_t low = xs_slice_local(static_cast<uint32_t>(src_sorted[k]), slice_shift) &
+                   ((1u << kXsLowBits) - 1u);
+    ent[k]       = (low << kXsRowBits) | rl;
     if (w_in) w_out[k] = w_in[e0 + e];
   }
   for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u <= n_units;
        u += (int64_t)gridDim.x * blockDim.x)
     unit_off_out[u] = static_cast<int64_t>(unit_off_in[u]);
+}
+
+// debug aid (CUGRAPH_AMD_XS_VERIFY=1): entries of a unit must ascend by source
+__global__ void xs_verify_kernel(uint32_t const* __restrict__ ent, int64_t const* __restrict__ unit_off,
+                                 int64_t n_units, unsigned long long* __restrict__ out)
+{
+  for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+    int64_t b = unit_off[u], e = unit_off[u + 1];
+    unsigned long long bad = 0, same = 0;
+    for (int64_t k = b + 1 + threadIdx.x; k < e; k += blockDim.x) {
+      uint32_t a0 = ent[k - 1] >> kXsRowBits, a1 = ent[k] >> kXsRowBits;
+      bad += a1 < a0;
+      same += a1 == a0;
+    }
+    if (bad) atomicAdd(out, bad);
+    if (same) atomicAdd(out + 1, same);
+    if (threadIdx.x == 0 && e > b) atomicAdd(out + 2, 1ull);
+  }
 }
 
 // hub work items: column i of the hub bucket is cut into ceil(deg / kHubChunk) pieces
@@ -860,7 +921,8 @@ struct PullPlan {
   bool xs_on{false};
   int64_t xs_row_first{0}, xs_n_rows{0}, xs_n_edges{0};
   int xs_n_tiles{0};
-  DevBuf xs_src, xs_rowl, xs_w, xs_unit_off, xs_tile_row;
+  int xs_n_win{1}, xs_slice_shift{7};
+  DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
   int64_t n_hub_items{0};
@@ -957,7 +1019,12 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
   int n_tiles     = static_cast<int>(n_tiles64);
-  int64_t n_units = static_cast<int64_t>(n_tiles) * kXsSlices;
+  // windows of 2^20 slice-local source positions, so that a packed entry needs only 20 source bits
+  uint32_t max_local = xs_slice_local(static_cast<uint32_t>(g.num_global_vertices - 1), slice_shift) |
+                       ((1u << slice_shift) - 1u);
+  int n_win          = static_cast<int>(max_local >> kXsLowBits) + 1;
+  int64_t n_units    = static_cast<int64_t>(n_tiles) * kXsSlices * n_win;
+  if (n_units >= 0x7fffffffLL) return;
   plan.xs_tile_row.alloc(static_cast<size_t>(n_tiles + 1) * 4);
   hipLaunchKernelGGL(xs_tiles_kernel, dim3(grid_for(n_rows + 1)), dim3(kThreads), 0, stream,
                      flags.as<unsigned int>(), pos.as<int64_t>(), n_rows,
@@ -968,14 +1035,13 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   DevBuf unit(static_cast<size_t>(ne) * 4), row_of_edge(static_cast<size_t>(ne) * 4);
   hipLaunchKernelGGL((xs_label_kernel<OffT>), dim3(grid_for(n_rows * 16)), dim3(kThreads), 0, stream,
                      offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(), slice_shift,
-                     unit.as<int32_t>(), row_of_edge.as<int32_t>());
+                     n_win, unit.as<int32_t>(), row_of_edge.as<int32_t>());
   CGA_HIP(hipGetLastError());
   CompressedOut c = compress_coo_perm(stream, n_units, g.num_global_vertices, ne, unit.as<int32_t>(),
                                       g.indices + e0);
   unit.release();
-  plan.xs_src = std::move(c.indices);
-  plan.xs_rowl.alloc(static_cast<size_t>(ne + 4) * sizeof(uint16_t));
-  CGA_HIP(hipMemsetAsync(plan.xs_rowl.p, 0, plan.xs_rowl.bytes, stream));
+  plan.xs_ent.alloc(static_cast<size_t>(ne + 4) * sizeof(uint32_t));
+  CGA_HIP(hipMemsetAsync(plan.xs_ent.p, 0, plan.xs_ent.bytes, stream));
   if (g.weights) {
     plan.xs_w.alloc(static_cast<size_t>(ne + 4) * sizeof(ValT));
     CGA_HIP(hipMemsetAsync(plan.xs_w.p, 0, plan.xs_w.bytes, stream));
@@ -987,8 +1053,8 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
                        stream, tile_of_row.as<int32_t>(), e0, ne, c.perm.as<uint32_t>(),
                        row_of_edge.as<int32_t>(), plan.xs_tile_row.as<int32_t>(),
                        static_cast<ValT const*>(g.weights), c.offsets.as<UOffT>(), n_units,
-                       plan.xs_rowl.as<uint16_t>(), plan.xs_w.as<ValT>(),
-                       plan.xs_unit_off.as<int64_t>());
+                       c.indices.as<int32_t>(), slice_shift, plan.xs_ent.as<uint32_t>(),
+                       plan.xs_w.as<ValT>(), plan.xs_unit_off.as<int64_t>());
   };
   if (c.off64)
     launch(int64_t{});
@@ -996,11 +1062,25 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     launch(int32_t{});
   CGA_HIP(hipGetLastError());
   CGA_HIP(hipStreamSynchronize(stream));
+  if (std::getenv("CUGRAPH_AMD_XS_VERIFY")) {
+    DevBuf out(24);
+    CGA_HIP(hipMemsetAsync(out.p, 0, 24, stream));
+    hipLaunchKernelGGL(xs_verify_kernel, dim3(4096), dim3(kThreads), 0, stream,
+                       plan.xs_ent.as<uint32_t>(), plan.xs_unit_off.as<int64_t>(), n_units,
+                       out.as<unsigned long long>());
+    unsigned long long h[3];
+    CGA_HIP(hipMemcpyAsync(h, out.p, 24, hipMemcpyDeviceToHost, stream));
+    CGA_HIP(hipStreamSynchronize(stream));
+    std::fprintf(stderr, "xs verify: tiles %d n_win %d units %lld non-empty %llu entries %lld descending pairs %llu equal pairs %llu\n",
+                 n_tiles, n_win, (long long)n_units, h[2], (long long)ne, h[0], h[1]);
+  }
   plan.xs_on        = true;
   plan.xs_row_first = row_first;
   plan.xs_n_rows    = n_rows;
   plan.xs_n_edges   = ne;
   plan.xs_n_tiles   = n_tiles;
+  plan.xs_n_win     = n_win;
+  plan.xs_slice_shift = slice_shift;
 }
 
 PullPlan& get_plan(Handle const& h, Graph& g)
@@ -1386,8 +1466,9 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   }
   if (s.xs_on) {
     PullPlan const& plan = *s.graph->plan;
-    a.xs.src       = plan.xs_src.as<int32_t>();
-    a.xs.rowl      = plan.xs_rowl.as<uint16_t>();
+    a.xs.ent       = plan.xs_ent.as<uint32_t>();
+    a.xs.n_win     = plan.xs_n_win;
+    a.xs.slice_shift = plan.xs_slice_shift;
     a.xs.w         = plan.xs_w.p ? plan.xs_w.as<ValT>() : nullptr;
     a.xs.unit_off  = plan.xs_unit_off.as<int64_t>();
     a.xs.tile_row  = plan.xs_tile_row.as<int32_t>();

@@ -1,12 +1,8 @@
 #!/bin/bash
-B="python3 -u bench.py --scale 26 --steps 5 --warmup 1 --no-cpu-baseline --no-convergence"
-run() { tag=$1; shift; env "$@" timeout -k 10 200 $B > gpurun_out/x_$tag.json 2>/dev/null || echo fail $tag; }
-run te256k CUGRAPH_AMD_XS_TILE_EDGES=262144
-run te4m CUGRAPH_AMD_XS_TILE_EDGES=4194304
-run te16m CUGRAPH_AMD_XS_TILE_EDGES=16777216
-run sh7 CUGRAPH_AMD_XS_SLICE_SHIFT=7
-run sh10 CUGRAPH_AMD_XS_SLICE_SHIFT=10
-run sh14 CUGRAPH_AMD_XS_SLICE_SHIFT=14
-run blk768 CUGRAPH_AMD_XS_BLOCKS=768
-run blk1280 CUGRAPH_AMD_XS_BLOCKS=1280
-echo xs-exp-ok
+B="bench.py --scale 26 --steps 3 --warmup 1 --no-cpu-baseline --no-convergence"
+export TMPDIR=/tmp
+export CUGRAPH_AMD_BUCKET_MASK=32
+rm -rf gpurun_out/pmc_a gpurun_out/pmc_b
+timeout -s KILL 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_a -- python3 $B > /dev/null 2>&1 || echo a-fail
+timeout -s KILL 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d gpurun_out/pmc_b -- python3 $B > /dev/null 2>&1 || echo b-fail
+echo pmc-ok
