@@ -38,13 +38,13 @@ namespace cga {
 namespace {
 
 constexpr int kThreads     = 256;
-constexpr int kNumBuckets  = 5;  // hub items, wave64, 16-lane, 4-lane, thread per vertex
+constexpr int kNumBuckets  = 5;  // hub items, wave64, 16-lane, thread per vertex, isolated
 constexpr int kMaxPartials = 16384;
 constexpr int64_t kHubChunk = 32768;  // edges of one hub work item (longer columns are split)
 
 // XS ("XCD-sliced, source-sorted") tiles for the mid-degree rows: see the comment at xs_bucket
 constexpr int kXsSlices       = 8;      // one slice of the source ids per XCD
-constexpr int64_t kXsTileEdges = 1 << 22;  // a tile is a run of rows holding about this many edges,
+constexpr int64_t kXsTileEdges = 1 << 23;  // a tile is a run of rows holding about this many edges,
 constexpr int kXsMaxRows      = 4096;     // but never more than this many rows (LDS accumulators)
 constexpr int kXsMinDegree    = 4;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
@@ -84,6 +84,7 @@ struct XsArgs {
   int block_begin, n_blocks;
   int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
   int dedupe;
+  uint32_t fake_hot;  // timing aid: sources below this slice-local position are not gathered
 };
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
@@ -304,6 +305,72 @@ __device__ inline void thread_bucket(IterArgs<OffT, ValT> const& a, Bucket const
   }
 }
 
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ inline void stream_load_vals4(float const* p, float* r)
+{
+  v4f_t v = __builtin_nontemporal_load(reinterpret_cast<v4f_t const*>(p));
+  r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+}
+__device__ inline void stream_load_vals4(double const* p, double* r)
+{
+  v2d_t v0 = __builtin_nontemporal_load(reinterpret_cast<v2d_t const*>(p));
+  v2d_t v1 = __builtin_nontemporal_load(reinterpret_cast<v2d_t const*>(p) + 1);
+  r[0] = v0.x; r[1] = v0.y; r[2] = v1.x; r[3] = v1.y;
+}
+__device__ inline void stream_store_vals4(float* p, float const* r)
+{
+  v4f_t v = {r[0], r[1], r[2], r[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(p));
+}
+__device__ inline void stream_store_vals4(double* p, double const* r)
+{
+  v2d_t v0 = {r[0], r[1]}, v1 = {r[2], r[3]};
+  __builtin_nontemporal_store(v0, reinterpret_cast<v2d_t*>(p));
+  __builtin_nontemporal_store(v1, reinterpret_cast<v2d_t*>(p) + 1);
+}
+
+// vertices without in-edges (about half of an R-MAT graph): no offsets, no gathers, the rank
+// update streamed four vertices per lane when the rows are a contiguous, aligned range
+template <typename OffT, typename ValT>
+__device__ inline void isolated_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b,
+                                       Epilogue<OffT, ValT>& ep)
+{
+  int64_t t = (int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x;
+  int64_t n = (int64_t)b.n_blocks * kThreads;
+  bool vec  = b.list == nullptr && a.pers_dense == nullptr && (a.vertex_first & 3) == 0;
+  if (!vec) {
+    for (int64_t i = t; i < b.count; i += n)
+      ep.finish(b.list ? static_cast<int64_t>(b.list[i]) : b.first + i, ValT(0));
+    return;
+  }
+  int64_t head = (4 - (b.first & 3)) & 3;
+  if (head > b.count) head = b.count;
+  int64_t nvec = (b.count - head) >> 2;
+  if (t < head) ep.finish(b.first + t, ValT(0));
+  for (int64_t i = head + 4 * nvec + t; i < b.count; i += n) ep.finish(b.first + i, ValT(0));
+  for (int64_t q = t; q < nvec; q += n) {
+    int64_t v = b.first + head + 4 * q;
+    ValT old[4], ow[4], prn[4], x[4];
+    stream_load_vals4(a.pr_old + v, old);
+    stream_load_vals4(a.out_w + v, ow);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ValT pe = ep.base + a.alpha * ValT(0);  // as Epilogue::finish with an empty sum
+      ep.delta += fabs(static_cast<double>(pe) - static_cast<double>(old[e]));
+      if (ow[e] == ValT(0)) {
+        ep.dangling += static_cast<double>(pe);
+        x[e] = pe;
+      } else {
+        x[e] = pe / ow[e];
+      }
+      prn[e] = pe;
+    }
+    stream_store_vals4(a.pr_new + v, prn);
+    stream_store_vals4(a.x_next + a.vertex_first + v, x);
+  }
+}
+
 // hubs: one workgroup per work item (a column, or a 32K-edge piece of a longer one); threads
 // stride the piece coalesced, partial sums staged through LDS; hub_finish_kernel adds the pieces
 template <typename OffT, typename ValT, bool WEIGHTED>
@@ -426,7 +493,7 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           uint32_t gi = ((loc[e] & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc[e] & low_mask);
-          xv[e]       = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
+          xv[e]       = (p[e] && loc[e] >= xs.fake_hot) ? a.x_cur[gi & a.gather_mask] : ValT(0);
         }
         if constexpr (WEIGHTED) {
 #pragma unroll
@@ -475,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void spmv_kernel(IterArgs<OffT, ValT> a)
   if (stop_check(a.ctrl, a.scal, a.epsilon, true)) return;
   Epilogue<OffT, ValT> ep(a);
   int blk = blockIdx.x;
-  // order in the launch: hub items, XS tiles, wave64, 16-lane, 4-lane, thread per vertex
+  // order in the launch: hub items, XS tiles, wave64, 16-lane, thread per vertex, isolated
   if (blk < a.buckets[0].block_begin + a.buckets[0].n_blocks) {
     hub_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[0]);
   } else if (blk < a.xs.block_begin + a.xs.n_blocks) {
@@ -485,9 +552,9 @@ __global__ __launch_bounds__(kThreads) void spmv_kernel(IterArgs<OffT, ValT> a)
   } else if (blk < a.buckets[2].block_begin + a.buckets[2].n_blocks) {
     group_bucket<16, OffT, ValT, WEIGHTED>(a, a.buckets[2], ep);
   } else if (blk < a.buckets[3].block_begin + a.buckets[3].n_blocks) {
-    group_bucket<4, OffT, ValT, WEIGHTED>(a, a.buckets[3], ep);
+    thread_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[3], ep);
   } else {
-    thread_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[4], ep);
+    isolated_bucket<OffT, ValT>(a, a.buckets[4], ep);
   }
   write_partials(ep.dangling, ep.delta, a.partials);
 }
@@ -936,8 +1003,8 @@ void destroy_plan(PullPlan* p) { delete p; }
 namespace {
 
 // [lo, hi) in-degree ranges, launch order: hubs, wave64, 16-lane groups, thread per vertex
-constexpr int64_t kBucketLo[kNumBuckets] = {kXsMaxDegree, 128, kXsMinDegree, 4, 0};
-constexpr int64_t kBucketHi[kNumBuckets] = {INT64_MAX, kXsMaxDegree, 128, kXsMinDegree, 4};
+constexpr int64_t kBucketLo[kNumBuckets] = {kXsMaxDegree, 128, kXsMinDegree, 1, 0};
+constexpr int64_t kBucketHi[kNumBuckets] = {INT64_MAX, kXsMaxDegree, 128, kXsMinDegree, 1};
 
 template <typename OffT>
 void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
@@ -1370,7 +1437,7 @@ void session_setup(Session& s, PagerankArgs const& a)
   // timing aid: CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets (results are then wrong)
   char const* mask_env = std::getenv("CUGRAPH_AMD_BUCKET_MASK");
   int bucket_mask      = mask_env ? std::atoi(mask_env) : 0x1F;
-  int const group_width[kNumBuckets] = {kThreads, 64, 16, 4, 1};
+  int const group_width[kNumBuckets] = {kThreads, 64, 16, 1, 1};
   int const block_cap[kNumBuckets]   = {4096, 3072, 3072, 2048, 2048};
   s.xs_on = plan.xs_on && ((bucket_mask >> 5) & 1 || !mask_env);
   for (int b = 0; b < kNumBuckets; ++b) {
@@ -1463,6 +1530,8 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.affinity_mode = am ? std::atoi(am) : 0;
     char const* dd      = std::getenv("CUGRAPH_AMD_XS_DEDUPE");
     a.xs.dedupe         = dd ? std::atoi(dd) : 1;
+    char const* fh      = std::getenv("CUGRAPH_AMD_XS_FAKE_HOT");
+    a.xs.fake_hot       = fh ? static_cast<uint32_t>(std::atoll(fh)) : 0u;
   }
   if (s.xs_on) {
     PullPlan const& plan = *s.graph->plan;

@@ -23,29 +23,8 @@ n_xs = int((deg >= 4).sum())
 print("xs rows", n_xs, "edges", int(off[n_xs]))
 outdeg = torch.bincount(idx.long(), minlength=nv)
 print("sources with out-degree 0:", int((outdeg == 0).sum()))
+tot = int(outdeg.sum())
+for thr in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19):
+    print("share of edges from the top", thr, "sources:", float(outdeg[:thr].sum()) / tot)
 for thr in (1 << 20, 1 << 22, 6 << 20, 1 << 23, 12 << 20, 1 << 24):
     print("edges from sources of rank >=", thr, ":", int(outdeg[thr:].sum()), " such sources with outdeg>0:", int((outdeg[thr:] > 0).sum()))
-# tiles
-r = torch.arange(n_xs, device="cuda")
-w = off[:n_xs] // (1 << 22)
-brk = torch.ones(n_xs, dtype=torch.bool, device="cuda")
-brk[1:] = (w[1:] != w[:-1])
-brk |= (r % 4096 == 0)
-tile_of_row = torch.cumsum(brk.long(), 0) - 1
-n_tiles = int(tile_of_row[-1]) + 1
-print("tiles", n_tiles)
-e_xs = int(off[n_xs])
-H = 6 << 20
-tot_pairs = 0; tot_cold = 0; pairs_big = 0; cold_big = 0
-CH = 1 << 27
-for e0 in range(0, e_xs, CH):
-    e1 = min(e0 + CH, e_xs)
-    s = idx[e0:e1].long()
-    rows = torch.searchsorted(off[1:n_xs + 1], torch.arange(e0, e1, device="cuda"), right=True)
-    t = tile_of_row[rows]
-    cold = s >= H
-    key = t[cold] * (1 << 22) + (s[cold] >> 5)
-    u = torch.unique(key)
-    tot_pairs += u.numel(); tot_cold += int(cold.sum())
-    del s, rows, t, cold, key, u
-print(f"H={H}: cold gathers {tot_cold}, distinct (tile,line) pairs (chunked upper bound) {tot_pairs}")
