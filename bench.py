@@ -32,7 +32,8 @@ def parse():
     p.add_argument("--edge-factor", type=int, default=16)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--scramble", type=int, default=1, help="scramble R-MAT vertex ids (0/1)")
-    p.add_argument("--cpu-scale", type=int, default=21, help="R-MAT scale of the CPU-baseline sample")
+    p.add_argument("--cpu-scale", type=int, default=24, help="R-MAT scale of the CPU-baseline sample")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of that sample")
     p.add_argument("--renumber", type=int, default=1,
                    help="build the graph with renumber=True, cugraph.Graph's default (0/1)")
     p.add_argument("--force-mg", action="store_true",
@@ -42,31 +43,87 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(args):
-    """The C oracle (a port of the reference's CPU pagerank_reference) on a bounded sample of the
-    same workload -- same generator, parameters and edge factor at a smaller scale -- timed on this
-    box's host cores.  Reported, not a target."""
+def _graph_to_host(graph):
+    """(offsets, indices) of a graph's compressed arrays as numpy (inputs of the CPU baseline)."""
+    import ctypes
+
     import numpy as np
 
+    from cugraph_amd import _capi
+    from cugraph_amd.session import _alias_device_memory
+
+    lib = _capi.load()
+    views = [ctypes.c_void_p() for _ in range(4)]
+    err = ctypes.c_void_p()
+    code = lib.cugraph_amd_graph_get_compressed(graph.c_graph_ptr, *[ctypes.byref(v) for v in views],
+                                                ctypes.byref(err))
+    _capi.check(code, err, "cugraph_amd_graph_get_compressed")
+    out = []
+    for v, dt in zip(views[:2], (None, np.int32)):
+        n = lib.cugraph_type_erased_device_array_view_size(v)
+        t = lib.cugraph_type_erased_device_array_view_type(v)
+        ptr = lib.cugraph_type_erased_device_array_view_pointer(v)
+        out.append(_alias_device_memory(ptr, n, np.int64 if t == 1 else np.int32).cpu().numpy())
+    for v in views:
+        if v:
+            lib.cugraph_type_erased_device_array_view_free(v)
+    return out[0].astype(np.int64), out[1]
+
+
+def cpu_baseline(args, handle, props):
+    """The C oracle (a port of the reference's CPU pagerank_reference, OpenMP over the host cores
+    of this box) on a bounded sample of the same workload -- same generator, parameters and edge
+    factor at a smaller scale -- sized to about 10-20 s of CPU work.  The sample's edges and CSC
+    are produced on the GPU (inputs only); what is timed is the oracle's iterations.  Reported,
+    not a target."""
+    import numpy as np
+    import torch
+
     import oracle
+    from cugraph_amd import generators, pylibcugraph as plc
 
     scale = args.cpu_scale
     nv, ne = 1 << scale, args.edge_factor << scale
-    src, dst = oracle.rmat_edges(scale, ne, seed=args.seed, scramble=bool(args.scramble))
-    off, idx, _ = oracle.compress(nv, dst, src)
-    iters = 8
-    t0 = time.perf_counter()
-    oracle.pagerank(nv, off, idx, None, dtype=np.float32, alpha=0.85, epsilon=0.0,
-                    max_iterations=iters)
-    dt = time.perf_counter() - t0
+    src, dst = generators.rmat(handle, scale, ne, seed=args.seed, scramble_vertex_ids=bool(args.scramble))
+    g = plc.SGGraph(handle, props, src, dst, store_transposed=True, renumber=False,
+                    vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    del src, dst
+    off, idx = _graph_to_host(g)
+    del g
+    torch.cuda.empty_cache()
+
+    def run(iters):
+        t0 = time.perf_counter()
+        oracle.pagerank(nv, off, idx, None, dtype=np.float32, alpha=0.85, epsilon=0.0,
+                        max_iterations=iters)
+        return time.perf_counter() - t0
+
+    t2, t6 = run(2), run(6)  # the difference is 4 iterations without the fixed set-up cost
+    iters = int(max(8, min(400, args.cpu_seconds / max((t6 - t2) / 4, 1e-3))))
+    dt = run(iters)
     return {
         "value": ne * iters / dt / 1e9,
         "unit": "GTEPS",
         "cores": oracle.num_threads(),
         "kind": "port",
-        "sample": f"R-MAT scale {scale} ef {args.edge_factor} ({ne} edges), {iters} iterations of the "
-                  f"OpenMP C oracle, {dt:.2f} s incl. out-degree pass; CSC build not timed",
+        "sample": f"R-MAT scale {scale} ef {args.edge_factor} ({ne} edges, natural vertex order), "
+                  f"{iters} iterations of the OpenMP C oracle in {dt:.1f} s incl. its out-degree pass; "
+                  "CSC build not timed",
     }
+
+
+def pmc_traffic(scale, ef, n_gpus):
+    """HBM bytes per spmv_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
+    None when they do not describe this workload.  bench.py cannot run under the profiler itself."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_spmv.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("scale") != scale or d.get("edge_factor") != ef or n_gpus != 1:
+        return None
+    return d.get("traffic_bytes_per_launch")
 
 
 def main():
@@ -161,7 +218,7 @@ def main():
     n_probe = min(args.steps, 10)
     iter_ms, kern_ms = inner.timed_iterate(n_probe) if not use_mg else mg.timed_iterate(sess, n_probe)
     kern_avg_ms = float(kern_ms.mean())
-    bytes_per_launch = info["bytes_per_iteration"]  # this rank's share for N > 1
+    bytes_per_launch = info["spmv_kernel_bytes"]  # this rank's share for N > 1
     achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm",
@@ -170,7 +227,8 @@ def main():
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
-        "traffic": None,
+        "traffic": pmc_traffic(scale, ef, world),
+        "traffic_source": "profiles/r1_pmc_spmv.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command)",
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "kernel_ms_avg": kern_avg_ms,
         "iteration_ms_event_avg": float(iter_ms.mean()),
@@ -179,7 +237,7 @@ def main():
     # ---------------- time to convergence at NetworkX tol = 1e-8 (epsilon = N * tol)
     conv = None
     if not args.no_convergence:
-        del sess
+        sess = inner = None
         eps = nv * 1e-8
         barrier()
         t0 = time.perf_counter()
@@ -227,7 +285,8 @@ def main():
                                          "spmv_workgroups")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+        sess = None
+        out["cpu_baseline"] = cpu_baseline(args, handle, props)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -1557,13 +1557,13 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   else
     hipLaunchKernelGGL((spmv_kernel<OffT, ValT, false>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
                        stream, a);
+  if (ev_kernel_end) CGA_HIP(hipEventRecord(ev_kernel_end, stream));  // spmv_kernel alone
   if (s.n_hub_blocks > 0)
     hipLaunchKernelGGL((hub_finish_kernel<OffT, ValT>), dim3(s.n_hub_blocks), dim3(kThreads), 0,
                        stream, a, s.hub_row_item_off, s.partials.as<double>() + 2 * s.n_spmv_blocks);
   if (s.n_xs_finish_blocks > 0)
     hipLaunchKernelGGL((xs_finish_kernel<OffT, ValT>), dim3(s.n_xs_finish_blocks), dim3(kThreads), 0,
                        stream, a, s.partials.as<double>() + 2 * (s.n_spmv_blocks + s.n_hub_blocks));
-  if (ev_kernel_end) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
   if (s.n_pers_blocks > 0)
     hipLaunchKernelGGL((pers_fix_kernel<ValT>), dim3(s.n_pers_blocks), dim3(kThreads), 0, stream,
                        s.pers_v.as<int32_t>(), s.pers_p.as<ValT>(), s.n_pers, a.pr_old, a.pr_new,
@@ -1736,7 +1736,10 @@ void session_info(Session& s, int64_t info[8])
   info[4]      = s.buckets[0].count;
   info[5]      = s.n_hub_items;
   info[6]      = s.n_spmv_blocks;
-  info[7]      = s.enqueued;
+  // algorithmic bytes of spmv_kernel alone: the rank update of the XS / hub rows (5 values per
+  // row) is done by xs_finish_kernel / hub_finish_kernel
+  int64_t finished_elsewhere = (s.xs_on ? s.graph->plan->xs_n_rows : 0) + s.buckets[0].count;
+  info[7]      = info[0] - 5 * finished_elsewhere * bval;
 }
 
 void session_exchange_buffers(Session& s, void** x_full, void** scalars)

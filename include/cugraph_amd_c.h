@@ -356,7 +356,8 @@ cugraph_error_code_t cugraph_amd_pagerank_session_result(cugraph_amd_pagerank_se
 
 /* info[0]=algorithmic bytes per iteration, [1]=edges per iteration,
  * [2]=low-degree vertices, [3]=mid-degree vertices, [4]=hub vertices, [5]=hub work items,
- * [6]=workgroups of the SpMV launch, [7]=reserved */
+ * [6]=workgroups of the SpMV launch, [7]=algorithmic bytes of the spmv_kernel launch alone (the
+ * rank update of rows whose sums are finished by xs_finish_kernel / hub_finish_kernel excluded) */
 cugraph_error_code_t cugraph_amd_pagerank_session_info(cugraph_amd_pagerank_session_t* session,
                                                        int64_t info[8], cugraph_error_t** error);
 
