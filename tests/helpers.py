@@ -71,3 +71,29 @@ def compressed_arrays(graph, handle):
                                                 ctypes.byref(nm), ctypes.byref(err))
     _capi.check(code, err, "cugraph_amd_graph_get_compressed")
     return tuple(view_to_numpy(handle, v) for v in (off, idx, w, nm))
+
+
+def compressed_tensors(graph):
+    """(offsets, indices, weights|None, number_map|None) as torch tensors ALIASING the graph's
+    device arrays (no copy; for the full-size property tests)."""
+    from cugraph_amd import _capi
+    from cugraph_amd.pylibcugraph.utils import get_numpy_type_from_c_type
+    from cugraph_amd.session import _alias_device_memory
+
+    lib = _capi.load()
+    views = [ctypes.c_void_p() for _ in range(4)]
+    err = ctypes.c_void_p()
+    code = lib.cugraph_amd_graph_get_compressed(graph.c_graph_ptr, *[ctypes.byref(v) for v in views],
+                                                ctypes.byref(err))
+    _capi.check(code, err, "cugraph_amd_graph_get_compressed")
+    out = []
+    for v in views:
+        if not v:
+            out.append(None)
+            continue
+        n = lib.cugraph_type_erased_device_array_view_size(v)
+        t = lib.cugraph_type_erased_device_array_view_type(v)
+        p = lib.cugraph_type_erased_device_array_view_pointer(v)
+        out.append(_alias_device_memory(p, n, get_numpy_type_from_c_type(t)))
+        lib.cugraph_type_erased_device_array_view_free(v)
+    return tuple(out)

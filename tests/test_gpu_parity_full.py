@@ -1,0 +1,174 @@
+"""GPU parity at BASELINE.json's full sizes.
+
+configs[1] (R-MAT scale 22, fp32, unweighted) and configs[2] (scale 24, fp64, weighted, 1k-vertex
+personalization) are small enough for the CPU oracle: ranks within north_star's max-abs bounds
+(1e-6 fp32 / 1e-10 fp64) at tol = 1e-8 and the same top-1000 ranking.  configs[3]'s graph (scale 26)
+is checked through size-independent properties: the CSC against checksums of the edge list, mass
+conservation, the fixed point, and agreement of the two independent SpMV paths (XS tiles vs
+degree buckets)."""
+import numpy as np
+import pytest
+
+from helpers import compressed_tensors, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _rmat_graph(scale, *, weighted=False, dtype=None, renumber=False, seed=42):
+    import torch
+    from cugraph_amd import generators, pylibcugraph as plc
+
+    h = plc.ResourceHandle()
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = generators.rmat(h, scale, ne, seed=seed, scramble_vertex_ids=True)
+    wgt = None
+    if weighted:
+        wgt = generators.rmat_weights(h, ne, seed=seed + 1, dtype=dtype)
+    g = plc.SGGraph(h, plc.GraphProperties(is_multigraph=True), src, dst, weight_array=wgt,
+                    store_transposed=True, renumber=renumber,
+                    vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    return h, g, src, dst, wgt
+
+
+def _top_k_agree(got, want, k, tol):
+    """Same top-k ranking; two vertices may swap only where the oracle's values differ by < tol."""
+    g = np.argsort(-got, kind="stable")[:k]
+    w = np.argsort(-want, kind="stable")[:k]
+    diff = g != w
+    assert np.all(np.abs(want[g[diff]] - want[w[diff]]) < tol), "top-k ranking differs beyond ties"
+
+
+def test_config1_scale22_fp32_unweighted_vs_oracle():
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    scale = 22
+    nv = 1 << scale
+    h, g, src, dst, _ = _rmat_graph(scale)
+    del src, dst
+    off, idx, _, _ = compressed_tensors(g)
+    off, idx = off.cpu().numpy().astype(np.int64), idx.cpu().numpy()
+    eps = nv * 1e-8
+    v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, eps, 500, False,
+                              fail_on_nonconvergence=False)
+    o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, None, dtype=np.float64, alpha=0.85,
+                                         epsilon=eps, max_iterations=500)
+    r = r.cpu().numpy().astype(np.float64)
+    assert conv and o_conv
+    assert np.max(np.abs(r - o_pr)) <= 1e-6  # north_star: fp32 max-abs
+    _top_k_agree(r, o_pr, 1000, 1e-7)
+    # a tighter epsilon, so that the comparison is not about where each side stopped
+    v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-5, 500, False,
+                              fail_on_nonconvergence=False)
+    o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, None, dtype=np.float64, alpha=0.85,
+                                         epsilon=1e-5, max_iterations=500)
+    r = r.cpu().numpy().astype(np.float64)
+    assert conv and o_conv
+    assert np.max(np.abs(r - o_pr)) <= 1e-6
+    _top_k_agree(r, o_pr, 1000, 1e-7)
+
+
+def test_config2_scale24_fp64_weighted_personalized_vs_oracle():
+    import torch
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    scale = 24
+    nv = 1 << scale
+    h, g, src, dst, wgt = _rmat_graph(scale, weighted=True, dtype=torch.float64)
+    del src, dst, wgt
+    off, idx, w, _ = compressed_tensors(g)
+    off, idx, w = off.cpu().numpy().astype(np.int64), idx.cpu().numpy(), w.cpu().numpy()
+    rng = np.random.default_rng(24)
+    pv = rng.permutation(nv)[:1000].astype(np.int32)
+    px = rng.random(1000) + 0.05
+    eps = nv * 1e-8
+    for e in (eps, 1e-4):
+        v, r = plc.personalized_pagerank(h, g, None, None, None, None, to_dev(pv), to_dev(px), 0.85,
+                                         e, 500, False)
+        o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, w, dtype=np.float64, alpha=0.85, epsilon=e,
+                                             max_iterations=500, pers_vertices=pv, pers_values=px)
+        r = r.cpu().numpy()
+        assert r.dtype == np.float64 and o_conv
+        assert np.max(np.abs(r - o_pr)) <= 1e-10  # north_star: fp64 max-abs
+        _top_k_agree(r, o_pr, 1000, 1e-12)
+        assert abs(r.sum() - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("renumber", [False, True])
+def test_config3_scale26_build_properties(renumber):
+    """COO -> CSC at 1.07 G edges: degree histogram, column order, and order-independent
+    checksums of the edge multiset (through number_map when renumbered)."""
+    import torch
+
+    scale = 26
+    nv, ne = 1 << scale, 16 << scale
+    h, g, src, dst, _ = _rmat_graph(scale, renumber=renumber)
+    off, idx, _, nmap = compressed_tensors(g)
+    assert off.numel() == nv + 1 and idx.numel() == ne
+    assert int(off[0]) == 0 and int(off[-1]) == ne
+    deg = off[1:] - off[:-1]
+    assert int(deg.min()) >= 0
+    if renumber:
+        assert bool((deg[:-1] >= deg[1:]).all())  # descending in-degree
+        assert nmap is not None and bool((torch.sort(nmap).values == torch.arange(nv, device="cuda", dtype=nmap.dtype)).all())
+        ext_of = nmap.long()
+        want_deg = torch.bincount(dst, minlength=nv)[ext_of]
+    else:
+        assert nmap is None
+        want_deg = torch.bincount(dst, minlength=nv)
+    assert bool((deg.long() == want_deg).all())
+    del want_deg
+    # sources ascend inside every column (by internal id)
+    starts = torch.zeros(ne + 1, dtype=torch.bool, device="cuda")
+    starts[off.long()] = True
+    assert not bool(((idx[1:] < idx[:-1]) & ~starts[1:ne]).any())
+    del starts
+    # checksum of the edge multiset: sum over edges of a mixed hash of (src, dst), mod 2^64
+    def checksum(s, d):
+        x = s.long() * 0x9E3779B1 + d.long() * 0x85EBCA77
+        x = (x ^ (x >> 15)) * 0x2C1B3C6D
+        return int(x.sum()), int((x ^ (x >> 13)).sum())
+
+    want = checksum(src, dst)
+    del src, dst
+    rows = torch.repeat_interleave(torch.arange(nv, device="cuda", dtype=torch.int32), deg.long())
+    if renumber:
+        got = checksum(nmap[idx.long()], nmap[rows.long()])
+    else:
+        got = checksum(idx, rows)
+    assert got == want
+
+
+def test_config3_scale26_pagerank_properties(monkeypatch):
+    """Full-size run: mass conservation, monotone L1 delta, fixed point, and the XS-tile path
+    against the degree-bucket path (independent kernels, same input) within the fp32 bound."""
+    import torch
+    from cugraph_amd import pylibcugraph as plc
+    from cugraph_amd.session import PagerankSession
+
+    scale = 26
+    nv = 1 << scale
+    results = {}
+    for path, xs in (("xs", "1"), ("buckets", "0")):
+        monkeypatch.setenv("CUGRAPH_AMD_XS", xs)
+        h2, g2, s2, d2, _ = _rmat_graph(scale, renumber=True)  # the plan is cached per graph
+        del s2, d2
+        sess = PagerankSession(h2, g2, alpha=0.85, epsilon=0.0)
+        deltas = []
+        for _ in range(12):
+            sess.iterate(1)
+            deltas.append(sess.status()[2])
+        assert all(b < a for a, b in zip(deltas, deltas[1:]))  # the power iteration contracts
+        assert deltas[-1] < deltas[0] * 0.85 ** 8
+        v, r, it, _ = sess.result(100)
+        assert it == 12
+        full = torch.empty(nv, dtype=torch.float64, device="cuda")
+        full[v.long()] = r.double()
+        results[path] = (full, deltas)
+        assert abs(float(full.sum()) - 1.0) < 1e-4  # dangling mass is redistributed, none lost
+        assert float(full.min()) > 0.0
+        del sess, g2
+    a, b = results["xs"][0], results["buckets"][0]
+    assert float((a - b).abs().max()) <= 1e-6
+    assert np.allclose(results["xs"][1], results["buckets"][1], rtol=1e-5)
