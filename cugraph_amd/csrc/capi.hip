@@ -70,10 +70,11 @@ bool is_float_type(cugraph_data_type_id_t t) { return t == FLOAT32 || t == FLOAT
 bool is_int_type(cugraph_data_type_id_t t) { return t == INT32 || t == INT64; }
 
 Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, ArrayView const* vertices,
-                  ArrayView const* src, ArrayView const* dst, ArrayView const* weights,
+                  ArrayView const* src_in, ArrayView const* dst_in, ArrayView const* weights_in,
                   bool store_transposed, bool renumber, bool drop_self_loops, bool drop_multi_edges,
                   int64_t vertex_first, int64_t vertex_last, int64_t num_global /* <0: single GPU */)
 {
+  ArrayView const *src = src_in, *dst = dst_in, *weights = weights_in;
   CGA_EXPECTS(src && dst, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src and dst are required.");
   CGA_EXPECTS(src->size == dst->size, CUGRAPH_INVALID_INPUT,
               "Invalid input arguments: src size != dst size.");
@@ -87,8 +88,21 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
               "vertex ids must be INT32 or INT64");
   CGA_EXPECTS(!weights || is_float_type(weights->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
               "edge weights must be FLOAT32 or FLOAT64");
-  CGA_EXPECTS(!drop_self_loops && !drop_multi_edges, CUGRAPH_NOT_IMPLEMENTED,
-              "drop_self_loops / drop_multi_edges are not implemented");
+  // graph_sg.cpp:185-208: hygiene on the edge list before anything else looks at it
+  std::vector<DevBuf> filtered;
+  ArrayView fsrc, fdst, fw;
+  if (drop_self_loops || drop_multi_edges) {
+    CGA_EXPECTS(num_global < 0, CUGRAPH_NOT_IMPLEMENTED,
+                "drop_self_loops / drop_multi_edges on a partitioned graph");
+    fsrc = *src;
+    fdst = *dst;
+    if (weights) fw = *weights;
+    filter_edgelist(h, drop_self_loops, drop_multi_edges, props && props->is_symmetric, renumber,
+                    vertices, fsrc, fdst, weights ? &fw : nullptr, filtered);
+    src = &fsrc;
+    dst = &fdst;
+    if (weights) weights = &fw;
+  }
 
   hipStream_t stream = h.stream;
   int64_t ne         = static_cast<int64_t>(src->size);

@@ -233,6 +233,11 @@ void partition_degree_order(hipStream_t stream, ArrayView const& dst, int64_t fi
                             int32_t* order_out, int32_t* rank_out);
 bool degrees_descending(hipStream_t stream, void const* offsets, bool off64, int64_t n);
 
+// edge_filter.hip: drop_self_loops / drop_multi_edges; the views are re-pointed at filtered copies
+void filter_edgelist(Handle const& h, bool drop_self_loops, bool drop_multi_edges, bool keep_min_weight,
+                     bool renumber, ArrayView const* vertices, ArrayView& src, ArrayView& dst,
+                     ArrayView* weights, std::vector<DevBuf>& hold);
+
 // out[i] = in[i] - shift  /  out[i] = (int64) in[i]
 void shift_ids(hipStream_t stream, int32_t const* in, int32_t* out, int64_t n, int64_t shift);
 void widen_ids(hipStream_t stream, int32_t const* in, int64_t* out, int64_t n);

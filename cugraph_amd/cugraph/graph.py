@@ -1,0 +1,151 @@
+"""cugraph.Graph for the PageRank path (reference: python/cugraph/cugraph/structure/graph_classes.py:
+107-170 from_cudf_edgelist, :360-430 from_pandas_edgelist; graph_implementation/simpleGraph.py:
+130-330 edge-list intake, :1120-1200 _make_plc_graph; structure/symmetrize.py:24-120).
+
+Only what `cugraph.pagerank` touches is here: edge-list intake with optional weights, the
+undirected => symmetrised convention, renumber / store_transposed, and the pylibcugraph graph."""
+import numpy as np
+
+
+class _EdgeList:
+    """what pagerank.py reads: `.weights` (bool) and `.edgelist_df` (src, dst[, weights])"""
+
+    def __init__(self, df, weighted):
+        self.edgelist_df = df
+        self.weights = weighted
+
+
+class Graph:
+    def __init__(self, m_graph=None, directed=False):
+        if m_graph is not None:
+            raise NotImplementedError("construction from another graph is outside the PageRank path")
+        self.graph_properties_directed = bool(directed)
+        self.multi = False
+        self.edgelist = None
+        self.store_transposed = False
+        self.renumbered = False
+        self._plc_graph = None
+        self._resource_handle = None
+        self._num_vertices = 0
+
+    # ------------------------------------------------------------------ queries
+    def is_directed(self):
+        return self.graph_properties_directed
+
+    def is_multigraph(self):
+        return self.multi
+
+    def is_weighted(self):
+        return bool(self.edgelist is not None and self.edgelist.weights)
+
+    def number_of_vertices(self):
+        return self._num_vertices
+
+    number_of_nodes = number_of_vertices
+
+    def number_of_edges(self, directed_edges=False):
+        n = len(self.edgelist.edgelist_df)
+        if self.is_directed() or directed_edges:
+            return n
+        df = self.edgelist.edgelist_df
+        loops = int((df["src"] == df["dst"]).sum())
+        return (n - loops) // 2 + loops
+
+    # ------------------------------------------------------------------ intake
+    def from_pandas_edgelist(self, pdf, source="source", destination="destination", edge_attr=None,
+                             weight=None, renumber=True, store_transposed=False,
+                             legacy_renum_only=False, vertices=None):
+        import pandas as pd
+
+        if not isinstance(pdf, pd.DataFrame):
+            raise TypeError("pdf input is not a Pandas DataFrame")
+        if self.edgelist is not None:
+            raise RuntimeError("Graph already has values")
+        for col in (source, destination):
+            if isinstance(col, (list, tuple)):
+                raise NotImplementedError("multi-column vertices are outside the PageRank path")
+            if col not in pdf.columns:
+                raise ValueError("source column names and/or destination column names not found in "
+                                 "input. Recheck the source and destination parameters")
+        wcol = edge_attr if edge_attr is not None else weight
+        if isinstance(wcol, (list, tuple)):
+            if len(wcol) != 1:
+                raise NotImplementedError("edge ids / edge types are outside the PageRank path")
+            wcol = wcol[0]
+        if wcol is not None and wcol not in pdf.columns:
+            raise ValueError("edge_attr column name not found in input. Recheck the edge_attr parameter")
+        df = pd.DataFrame({"src": pdf[source].to_numpy(), "dst": pdf[destination].to_numpy()})
+        if df["src"].dtype != df["dst"].dtype:
+            raise ValueError("source and destination columns must have the same dtype")
+        if df["src"].dtype.kind not in "iu":
+            raise NotImplementedError("non-integer vertex ids are outside the PageRank path")
+        if df["src"].dtype not in (np.int32, np.int64):
+            df = df.astype({"src": np.int64, "dst": np.int64})
+        if wcol is not None:
+            w = pdf[wcol].to_numpy()
+            if w.dtype not in (np.float32, np.float64):
+                w = w.astype(np.float64)
+            df["weights"] = w
+        if not self.is_directed():
+            df = _symmetrize(df, self.multi)
+        elif not self.multi:
+            # simpleGraph.py:306-312: a Graph (not MultiGraph) drops parallel edges
+            df = _drop_multi(df)
+        self.edgelist = _EdgeList(df, wcol is not None)
+        self.store_transposed = bool(store_transposed)
+        self.renumbered = bool(renumber)
+        self._vertices = None if vertices is None else np.asarray(vertices, dtype=df["src"].dtype)
+        self._make_plc_graph()
+        return self
+
+    # cuDF is CUDA-only; the method name is kept so reference call sites read the same
+    from_cudf_edgelist = from_pandas_edgelist
+
+    def from_numpy_array(self, np_array, nodes=None):
+        import pandas as pd
+
+        a = np.asarray(np_array)
+        src, dst = np.nonzero(a)
+        pdf = pd.DataFrame({"src": src.astype(np.int32), "dst": dst.astype(np.int32),
+                            "weight": a[src, dst].astype(np.float64)})
+        return self.from_pandas_edgelist(pdf, "src", "dst", "weight", renumber=False)
+
+    def _make_plc_graph(self):
+        import torch
+
+        from .. import pylibcugraph as plc
+
+        df = self.edgelist.edgelist_df
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        self._resource_handle = plc.ResourceHandle()
+        props = plc.GraphProperties(is_symmetric=not self.is_directed(), is_multigraph=self.multi)
+        src, dst = dev(df["src"].to_numpy()), dev(df["dst"].to_numpy())
+        wgt = dev(df["weights"].to_numpy()) if self.edgelist.weights else None
+        verts = None if self._vertices is None else dev(self._vertices)
+        self._plc_graph = plc.SGGraph(self._resource_handle, props, src, dst, weight_array=wgt,
+                                      store_transposed=self.store_transposed,
+                                      renumber=self.renumbered, do_expensive_check=False,
+                                      vertices_array=verts)
+        self._num_vertices = self._plc_graph.info()["num_vertices"]
+
+
+class MultiGraph(Graph):
+    def __init__(self, directed=False):
+        super().__init__(directed=directed)
+        self.multi = True
+
+
+def _drop_multi(df):
+    """one edge per (src, dst); the minimum weight survives (symmetrize.py:100-108 groupby.min)"""
+    if "weights" in df.columns:
+        return df.groupby(["src", "dst"], as_index=False, sort=False).min()
+    return df.drop_duplicates(["src", "dst"], ignore_index=True)
+
+
+def _symmetrize(df, multi):
+    """undirected graph: both directions of every edge (symmetrize.py:24-120)"""
+    import pandas as pd
+
+    rev = df.rename(columns={"src": "dst", "dst": "src"})[list(df.columns)]
+    out = pd.concat([df, rev], ignore_index=True)
+    return out if multi else _drop_multi(out)

@@ -1,0 +1,226 @@
+"""cugraph-level API (cugraph_amd.cugraph): the reference's own wrapper tests restated
+(python/cugraph/cugraph/tests/link_analysis/test_pagerank.py:205-212, 367-469), NetworkX as the
+oracle, plus drop_self_loops / drop_multi_edges of the graph build."""
+import networkx as nx
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import compressed_arrays, load_csv, make_sg_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _karate_frame():
+    src, dst, wgt = load_csv("karate.csv")
+    return pd.DataFrame({"src": src, "dst": dst, "weights": wgt})
+
+
+def _directed_graph(store_transposed=True, weighted=True, renumber=True):
+    from cugraph_amd import cugraph
+
+    G = cugraph.Graph(directed=True)
+    G.from_cudf_edgelist(_karate_frame(), source="src", destination="dst",
+                         edge_attr="weights" if weighted else None,
+                         store_transposed=store_transposed, renumber=renumber)
+    return G
+
+
+def _nx_digraph():
+    src, dst, wgt = load_csv("karate.csv")
+    G = nx.DiGraph()
+    G.add_weighted_edges_from(zip(src.tolist(), dst.tolist(), wgt.tolist()))
+    return G
+
+
+@pytest.mark.parametrize("renumber", [True, False])
+def test_pagerank_frame_matches_networkx(renumber):
+    from cugraph_amd import cugraph
+
+    G = _directed_graph(renumber=renumber)
+    assert G.number_of_vertices() == 34 and G.number_of_edges() == 156
+    df = cugraph.pagerank(G, alpha=0.85, max_iter=500, tol=1.0e-7)
+    assert list(df.columns) == ["vertex", "pagerank"] and len(df) == 34
+    want = nx.pagerank(_nx_digraph(), alpha=0.85, tol=1e-9, max_iter=500)
+    got = dict(zip(df["vertex"].tolist(), df["pagerank"].tolist()))
+    assert set(got) == set(want)
+    # the reference's own criterion is |diff| < 1.1 * tol for 99 % of the vertices; all here
+    assert max(abs(got[v] - want[v]) for v in want) < 1e-6
+
+
+def test_pagerank_personalization_nstart_frames():
+    from cugraph_amd import cugraph
+
+    G = _directed_graph()
+    pers = pd.DataFrame({"vertex": np.array([17, 26], np.int32),
+                         "values": np.array([0.5, 0.75], np.float32)})
+    nstart = pd.DataFrame({"vertex": np.arange(34, dtype=np.int32),
+                           "values": np.full(34, 1 / 34, np.float32)})
+    df = cugraph.pagerank(G, personalization=pers, nstart=nstart, max_iter=500, tol=1e-7)
+    want = nx.pagerank(_nx_digraph(), alpha=0.85, tol=1e-9, max_iter=500,
+                       personalization={17: 0.5, 26: 0.75})
+    got = dict(zip(df["vertex"].tolist(), df["pagerank"].tolist()))
+    assert max(abs(got[v] - want[v]) for v in want) < 1e-6
+    # precomputed out-weight sums: the true sums change nothing
+    src, _, wgt = load_csv("karate.csv")
+    sums = np.bincount(src, weights=wgt.astype(np.float64), minlength=34).astype(np.float32)
+    pre = pd.DataFrame({"vertex": np.arange(34, dtype=np.int32), "sums": sums})
+    df2 = cugraph.pagerank(G, personalization=pers, precomputed_vertex_out_weight=pre,
+                           max_iter=500, tol=1e-7)
+    got2 = dict(zip(df2["vertex"].tolist(), df2["pagerank"].tolist()))
+    assert max(abs(got2[v] - want[v]) for v in want) < 1e-6
+
+
+def test_pagerank_invalid_personalization_dtype():
+    """test_pagerank.py:367-410, same message texts"""
+    from cugraph_amd import cugraph
+
+    G = _directed_graph()
+    personalization = pd.DataFrame({"vertex": [17, 26], "values": [0.5, 0.75]})  # int64 / float64
+    warning_msg = (
+        "PageRank requires 'personalization' values to match the "
+        "graph's 'edge_attr' type. edge_attr type is: "
+        "float32 and got 'personalization' values "
+        "of type: float64."
+    )
+    with pytest.warns(UserWarning, match=warning_msg):
+        cugraph.pagerank(G, personalization=personalization)
+    warning_msg = (
+        "PageRank requires 'personalization' vertex to match the "
+        "graph's 'vertex' type. input graph's vertex type is: "
+        "int32 and got 'personalization' vertex "
+        "of type: int64."
+    )
+    with pytest.warns(UserWarning, match=warning_msg):
+        cugraph.pagerank(G, personalization=personalization)
+    with pytest.raises(NotImplementedError):
+        cugraph.pagerank(G, personalization={17: 0.5})
+
+
+def test_pagerank_transposed_false():
+    """test_pagerank.py:413-424; the result is the same as with store_transposed=True"""
+    from cugraph_amd import cugraph
+
+    G = _directed_graph(store_transposed=False)
+    warning_msg = (
+        "Pagerank expects the 'store_transposed' "
+        "flag to be set to 'True' for optimal performance during "
+        "the graph creation"
+    )
+    with pytest.warns(UserWarning, match=warning_msg):
+        df = cugraph.pagerank(G, tol=1e-7, max_iter=500)
+    ref = cugraph.pagerank(_directed_graph(), tol=1e-7, max_iter=500)
+    a = df.sort_values("vertex")["pagerank"].to_numpy()
+    b = ref.sort_values("vertex")["pagerank"].to_numpy()
+    assert np.max(np.abs(a - b)) < 1e-7
+
+
+def test_pagerank_non_convergence():
+    """test_pagerank.py:427-469"""
+    from cugraph_amd import cugraph
+
+    G = _directed_graph()
+    with pytest.raises(cugraph.exceptions.FailedToConvergeError):
+        cugraph.pagerank(G, max_iter=1, fail_on_nonconvergence=True)
+    (df, converged) = cugraph.pagerank(G, max_iter=1, fail_on_nonconvergence=False)
+    assert type(df) is pd.DataFrame and type(converged) is bool and converged is False
+    (df, converged) = cugraph.pagerank(G, fail_on_nonconvergence=False)
+    assert type(df) is pd.DataFrame and type(converged) is bool and converged is True
+    personalization = pd.DataFrame({"vertex": np.array([17, 26], np.int32),
+                                    "values": np.array([0.5, 0.75], np.float32)})
+    with pytest.raises(cugraph.exceptions.FailedToConvergeError):
+        cugraph.pagerank(G, max_iter=1, personalization=personalization, fail_on_nonconvergence=True)
+    (df, converged) = cugraph.pagerank(G, max_iter=1, personalization=personalization,
+                                       fail_on_nonconvergence=False)
+    assert converged is False
+    (df, converged) = cugraph.pagerank(G, personalization=personalization,
+                                       fail_on_nonconvergence=False)
+    assert converged is True
+
+
+def test_undirected_graph_and_networkx_input():
+    """cugraph.Graph() is undirected: edges are symmetrised; a NetworkX graph in, a dict out"""
+    from cugraph_amd import cugraph
+
+    kc = nx.karate_club_graph()
+    want = nx.pagerank(kc, alpha=0.85, tol=1e-10, max_iter=500, weight=None)
+    edges = np.array(list(kc.edges()), dtype=np.int32)
+    G = cugraph.Graph()
+    G.from_pandas_edgelist(pd.DataFrame({"source": edges[:, 0], "destination": edges[:, 1]}),
+                           store_transposed=True)
+    assert not G.is_directed() and G.number_of_edges() == kc.number_of_edges()
+    df = cugraph.pagerank(G, tol=1e-7, max_iter=500)
+    got = dict(zip(df["vertex"].tolist(), df["pagerank"].tolist()))
+    assert max(abs(got[v] - want[v]) for v in want) < 1e-6
+    d = cugraph.pagerank(kc, tol=1e-7, max_iter=500)  # NetworkX graph in
+    assert isinstance(d, dict) and set(d) == set(want)
+    assert max(abs(d[v] - want[v]) for v in want) < 1e-6
+
+
+@pytest.mark.parametrize("directed", [False, True])
+def test_nx_backend_entry(directed):
+    """nx-cugraph's pagerank (pagerank_alg.py:35-96) against NetworkX itself, NetworkX arguments"""
+    from cugraph_amd import cugraph
+
+    G = nx.les_miserables_graph()  # string node names, weighted
+    if directed:
+        G = nx.DiGraph([(u, v, d) for u, v, d in G.edges(data=True) if hash(u) % 3])
+    pers = {n: float(i % 5 + 1) for i, n in enumerate(G) if i % 7 == 0}
+    nstart = {n: float(i % 3 + 1) for i, n in enumerate(G)}
+    for kw in ({}, {"personalization": pers}, {"nstart": nstart}, {"weight": None}):
+        want = nx.pagerank(G, alpha=0.9, tol=1e-10, max_iter=1000, **kw)
+        got = cugraph.nx_pagerank(G, alpha=0.9, tol=1e-9, max_iter=1000, dtype=np.float64, **kw)
+        assert set(got) == set(want)
+        assert max(abs(got[n] - want[n]) for n in want) < 1e-7
+    with pytest.raises(nx.PowerIterationFailedConvergence):
+        cugraph.nx_pagerank(G, max_iter=2, tol=1e-12)
+    with pytest.raises(ZeroDivisionError):
+        cugraph.nx_pagerank(G, personalization={n: 0 for n in G})
+    assert cugraph.nx_pagerank(nx.DiGraph()) == {}
+
+
+@pytest.mark.parametrize("name", ["karate_multi_edge.csv", "karate_s_loop.csv"])
+@pytest.mark.parametrize("renumber", [False, True])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_drop_self_loops_and_multi_edges(name, renumber, symmetric):
+    """graph_sg.cpp:185-208: self-loops dropped, one copy of every parallel edge kept (the minimum
+    weight when the graph is flagged symmetric, the first in input order otherwise)"""
+    import torch
+    from cugraph_amd import pylibcugraph as plc
+
+    src, dst, wgt = load_csv(name)
+    rng = np.random.default_rng(1)
+    wgt = (wgt * rng.integers(1, 5, len(wgt))).astype(np.float32)  # make the copies differ
+    # add explicit copies and loops so that both flags have work in both files
+    src = np.concatenate([src, src[:20], np.array([3, 3, 9], np.int32)])
+    dst = np.concatenate([dst, dst[:20], np.array([3, 3, 9], np.int32)])
+    wgt = np.concatenate([wgt, (wgt[:20] * 0.5).astype(np.float32), np.array([1, 2, 3], np.float32)])
+    nv = int(max(src.max(), dst.max())) + 1
+    h = plc.ResourceHandle()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    g = plc.SGGraph(h, plc.GraphProperties(is_symmetric=symmetric, is_multigraph=False), dev(src),
+                    dev(dst), weight_array=dev(wgt), store_transposed=True, renumber=renumber,
+                    vertices_array=dev(np.arange(nv, dtype=np.int32)), drop_self_loops=True,
+                    drop_multi_edges=True)
+    off, idx, w, nmap = compressed_arrays(g, h)
+    # expected edge set on the host
+    keep = src != dst
+    s, d, x = src[keep], dst[keep], wgt[keep]
+    best = {}
+    for i in range(len(s)):
+        k = (int(s[i]), int(d[i]))
+        if k not in best or (symmetric and x[i] < best[k]):
+            best[k] = x[i]
+    assert len(idx) == len(best) and int(off[-1]) == len(best)
+    ext = nmap if nmap is not None else np.arange(nv)
+    rows = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    got = {(int(ext[idx[k]]), int(ext[rows[k]])): w[k] for k in range(len(idx))}
+    assert got == best
+    # PageRank on it equals NetworkX on the simple weighted digraph
+    G = nx.DiGraph()
+    G.add_nodes_from(range(nv))
+    G.add_weighted_edges_from((a, b, float(v)) for (a, b), v in best.items())
+    want = nx.pagerank(G, alpha=0.85, tol=1e-10, max_iter=500)
+    v, r = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-7, 500, False)
+    got_pr = dict(zip(v.cpu().numpy().tolist(), r.cpu().numpy().tolist()))
+    assert max(abs(got_pr[n] - want[n]) for n in want) < 1e-6
