@@ -112,6 +112,55 @@ def cpu_baseline(args, handle, props):
     }
 
 
+def other_cpu_baselines(args, handle):
+    """north_star asks for NetworkX / SciPy PageRank timed on this box's host cores beside the GPU
+    number: (i) networkx.pagerank itself at a scale its Python graph object can take, (ii) the
+    SciPy restatement of its `_pagerank_scipy` loop (single-threaded CSR mat-vec) on a larger
+    sample.  Reported, not targets."""
+    import numpy as np
+
+    import oracle
+    from cugraph_amd import generators
+
+    out = []
+    try:
+        scale = 20
+        nv, ne = 1 << scale, args.edge_factor << scale
+        src, dst = generators.rmat(handle, scale, ne, seed=args.seed, scramble_vertex_ids=bool(args.scramble))
+        src, dst = src.cpu().numpy(), dst.cpu().numpy()
+
+        def run(iters):
+            t0 = time.perf_counter()
+            try:
+                oracle.scipy_pagerank(nv, src, dst, alpha=0.85, tol=0.0, max_iter=iters)
+            except RuntimeError:  # tol = 0 never converges: exactly `iters` iterations ran
+                pass
+            return time.perf_counter() - t0
+
+        t2, t12 = run(2), run(12)
+        per = max((t12 - t2) / 10, 1e-6)
+        out.append({"value": ne / per / 1e9, "unit": "GTEPS", "cores": 1, "kind": "port",
+                    "sample": f"SciPy restatement of networkx _pagerank_scipy, R-MAT scale {scale} ef "
+                              f"{args.edge_factor} ({ne} edges): {per * 1e3:.1f} ms/iteration (CSR mat-vec is "
+                              f"single-threaded; {os.cpu_count()} cores available), CSR build + "
+                              f"normalisation {t2 - 2 * per:.2f} s not counted"})
+        scale = 14
+        nv, ne = 1 << scale, args.edge_factor << scale
+        src, dst = generators.rmat(handle, scale, ne, seed=args.seed, scramble_vertex_ids=bool(args.scramble))
+        src, dst = src.cpu().numpy(), dst.cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.nx_pagerank(nv, src, dst, alpha=0.85, tol=1e-8, max_iter=500)
+        dt = time.perf_counter() - t0
+        _, iters = oracle.scipy_pagerank(nv, src, dst, alpha=0.85, tol=1e-8, max_iter=500, return_info=True)
+        out.append({"value": ne * iters / dt / 1e9, "unit": "GTEPS", "cores": 1, "kind": "reference-oracle",
+                    "sample": f"networkx.pagerank (the oracle north_star names) on a MultiDiGraph, R-MAT scale "
+                              f"{scale} ef {args.edge_factor} ({ne} edges), tol 1e-8: {dt:.2f} s for graph "
+                              f"object + {iters} iterations"})
+    except Exception as exc:  # a reported extra must never cost the bench line
+        out.append({"error": repr(exc)})
+    return out
+
+
 def pmc_traffic(scale, ef, n_gpus):
     """HBM bytes per spmv_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
     None when they do not describe this workload.  bench.py cannot run under the profiler itself."""
@@ -287,6 +336,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sess = None
         out["cpu_baseline"] = cpu_baseline(args, handle, props)
+        out["cpu_baselines_networkx_scipy"] = other_cpu_baselines(args, handle)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

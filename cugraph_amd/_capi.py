@@ -87,6 +87,9 @@ SIGNATURES = {
     "cugraph_amd_create_resource_handle": (_vp, [_vp, _int, _int]),
     "cugraph_amd_graph_create_local": (_int, [_vp, ctypes.POINTER(GraphPropertiesStruct), _vp, _vp,
                                               _vp, _i64, _i64, _i64, _vpp, _vpp]),
+    "cugraph_amd_graph_create_local_compact": (_int, [_vp, ctypes.POINTER(GraphPropertiesStruct), _vp, _vp,
+                                                        _vp, _i64, _i64, _i64, _i64, _vp, _vpp, _vpp]),
+    "cugraph_amd_edgelist_source_weight_sums": (_int, [_vp, _vp, _vp, _vp, _vpp]),
     "cugraph_amd_partition_degree_order": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vpp]),
     "cugraph_amd_graph_info": (_int, [_vp, ctypes.POINTER(_i64), _vpp]),
     "cugraph_amd_graph_get_compressed": (_int, [_vp, _vpp, _vpp, _vpp, _vpp, _vpp]),

@@ -21,6 +21,8 @@ void session_destroy(Session* s);
 bool session_is_f64(Session& s);
 int64_t session_num_global(Session& s);
 void compute_source_sums(hipStream_t stream, Graph const& g, double* sums);
+void edgelist_source_sums(hipStream_t stream, ArrayView const& src, ArrayView const* weights,
+                          int64_t num_vertices, double* sums);
 }  // namespace cga
 
 using namespace cga;
@@ -72,7 +74,8 @@ bool is_int_type(cugraph_data_type_id_t t) { return t == INT32 || t == INT64; }
 Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, ArrayView const* vertices,
                   ArrayView const* src_in, ArrayView const* dst_in, ArrayView const* weights_in,
                   bool store_transposed, bool renumber, bool drop_self_loops, bool drop_multi_edges,
-                  int64_t vertex_first, int64_t vertex_last, int64_t num_global /* <0: single GPU */)
+                  int64_t vertex_first, int64_t vertex_last, int64_t num_global /* <0: single GPU */,
+                  int64_t num_source_slots = 0, ArrayView const* x_pos = nullptr)
 {
   ArrayView const *src = src_in, *dst = dst_in, *weights = weights_in;
   CGA_EXPECTS(src && dst, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src and dst are required.");
@@ -130,13 +133,27 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
                 CUGRAPH_INVALID_INPUT, "invalid local vertex range");
     CGA_EXPECTS(ne == 0 || (dmin >= vertex_first && dmax < vertex_last), CUGRAPH_INVALID_INPUT,
                 "destination ids outside this rank's vertex range");
-    CGA_EXPECTS(ne == 0 || (smin >= 0 && smax < num_global), CUGRAPH_INVALID_INPUT,
-                "source ids outside [0, num_global_vertices)");
+    int64_t minor_space = num_source_slots > 0 ? num_source_slots : num_global;
+    CGA_EXPECTS(ne == 0 || (smin >= 0 && smax < minor_space), CUGRAPH_INVALID_INPUT,
+                num_source_slots > 0 ? "source slots outside [0, num_source_slots)"
+                                     : "source ids outside [0, num_global_vertices)");
     g->num_vertices        = vertex_last - vertex_first;
     g->num_global_vertices = num_global;
     g->vertex_first        = vertex_first;
+    if (num_source_slots > 0) {
+      CGA_EXPECTS(x_pos && x_pos->type == INT32 &&
+                    static_cast<int64_t>(x_pos->size) == g->num_vertices,
+                  CUGRAPH_INVALID_INPUT, "x_pos must be an INT32 view with one entry per local vertex");
+      CGA_EXPECTS(num_source_slots < 0x7fffffffLL, CUGRAPH_INVALID_INPUT, "too many source slots");
+      g->num_source_slots = num_source_slots;
+      size_t bytes        = static_cast<size_t>(g->num_vertices > 0 ? g->num_vertices : 1) * 4;
+      CGA_HIP(hipMalloc(reinterpret_cast<void**>(&g->x_pos), bytes));
+      if (g->num_vertices > 0)
+        CGA_HIP(hipMemcpyAsync(g->x_pos, x_pos->data, static_cast<size_t>(g->num_vertices) * 4,
+                               hipMemcpyDeviceToDevice, stream));
+    }
     n_major                = g->num_vertices;
-    n_minor                = num_global;
+    n_minor                = minor_space;
     major_shift            = vertex_first;
   } else if (renumber) {
     // create_graph_from_edgelist_impl.cuh:925-941: ids become 0..V-1 by descending major degree
@@ -589,6 +606,50 @@ cugraph_error_code_t cugraph_amd_graph_create_local(
                           as<ArrayView>(dst), as<ArrayView>(weights), true, false, false, false,
                           vertex_first, vertex_last, num_global_vertices);
     *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_graph_create_local_compact(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src_slots,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights, int64_t vertex_first,
+  int64_t vertex_last, int64_t num_global_vertices, int64_t num_source_slots,
+  const cugraph_type_erased_device_array_view_t* x_pos, cugraph_graph_t** graph,
+  cugraph_error_t** error)
+{
+  if (graph) *graph = nullptr;
+  if (error) *error = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph) return fail(error, CUGRAPH_INVALID_INPUT, "graph pointer is NULL");
+  return guarded(error, [&] {
+    CGA_EXPECTS(num_global_vertices >= 0 && num_source_slots > 0, CUGRAPH_INVALID_INPUT,
+                "num_global_vertices must be >= 0 and num_source_slots > 0");
+    Graph* g = make_graph(*as<Handle>(handle), properties, nullptr, as<ArrayView>(src_slots),
+                          as<ArrayView>(dst), as<ArrayView>(weights), true, false, false, false,
+                          vertex_first, vertex_last, num_global_vertices, num_source_slots,
+                          as<ArrayView>(x_pos));
+    *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_edgelist_source_weight_sums(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* weights,
+  cugraph_type_erased_device_array_view_t* sums, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto const* s = as<ArrayView>(src);
+    auto const* w = as<ArrayView>(weights);
+    auto* out     = as<ArrayView>(sums);
+    CGA_EXPECTS(s && out, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(is_int_type(s->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "src must be INT32 or INT64");
+    CGA_EXPECTS(!w || (is_float_type(w->type) && w->size == s->size), CUGRAPH_INVALID_INPUT,
+                "weights must be FLOAT32/FLOAT64 with one entry per edge");
+    CGA_EXPECTS(out->type == FLOAT64, CUGRAPH_INVALID_INPUT, "sums must be FLOAT64");
+    edgelist_source_sums(as<Handle>(handle)->stream, *s, w, static_cast<int64_t>(out->size),
+                         static_cast<double*>(out->data));
   });
 }
 

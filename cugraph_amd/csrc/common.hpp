@@ -156,6 +156,10 @@ struct Graph {
   int64_t num_vertices{0};         // majors held here (SG: all vertices)
   int64_t num_global_vertices{0};  // id space of the minors (== num_vertices on one GPU)
   int64_t vertex_first{0};         // first global id of the local major range (1D partition)
+  // compact source space (multi-GPU): minors are SLOTS of the gathered vector, [0, num_source_slots),
+  // and x_pos[row] is the slot row's own value goes to (-1: no edge leaves it, nobody gathers it)
+  int64_t num_source_slots{0};     // 0: minors are vertex ids in [0, num_global_vertices)
+  int32_t* x_pos{nullptr};
   int64_t num_edges{0};
   bool off64{false};
 
@@ -171,6 +175,7 @@ struct Graph {
 
   PullPlan* plan{nullptr};  // cached by the first PageRank call on this graph
 
+  int64_t minor_space() const { return num_source_slots > 0 ? num_source_slots : num_global_vertices; }
   ~Graph();
 };
 

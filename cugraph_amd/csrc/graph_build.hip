@@ -638,6 +638,7 @@ Graph::~Graph()
   if (weights) (void)hipFree(weights);
   if (number_map) (void)hipFree(number_map);
   if (ext_lookup) (void)hipFree(ext_lookup);
+  if (x_pos) (void)hipFree(x_pos);
   if (plan) destroy_plan(plan);
 }
 

@@ -128,6 +128,7 @@ struct IterArgs {
   int personalized;
   uint32_t gather_mask;  // 0xFFFFFFFF; a timing aid can narrow it (CUGRAPH_AMD_GATHER_MASK)
   int64_t vertex_first;
+  int32_t const* x_pos;  // slot of row v in the gathered vector, -1: nobody gathers it; nullptr: vertex_first + v
   HubItem const* hub_items;  // bucket 0 works on these instead of whole rows
   int64_t n_hub_items;
   double* hub_item_partial;
@@ -184,7 +185,12 @@ struct Epilogue {
       x = pr / ow;
     }
     __builtin_nontemporal_store(pr, a.pr_new + v);
-    __builtin_nontemporal_store(x, a.x_next + a.vertex_first + v);
+    if (a.x_pos) {
+      int32_t slot = a.x_pos[v];
+      if (slot >= 0) a.x_next[slot] = x;
+    } else {
+      __builtin_nontemporal_store(x, a.x_next + a.vertex_first + v);
+    }
   }
 };
 
@@ -338,7 +344,8 @@ __device__ inline void isolated_bucket(IterArgs<OffT, ValT> const& a, Bucket con
 {
   int64_t t = (int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x;
   int64_t n = (int64_t)b.n_blocks * kThreads;
-  bool vec  = b.list == nullptr && a.pers_dense == nullptr && (a.vertex_first & 3) == 0;
+  bool vec  = b.list == nullptr && a.pers_dense == nullptr && a.x_pos == nullptr &&
+             (a.vertex_first & 3) == 0;
   if (!vec) {
     for (int64_t i = t; i < b.count; i += n)
       ep.finish(b.list ? static_cast<int64_t>(b.list[i]) : b.first + i, ValT(0));
@@ -737,7 +744,8 @@ __global__ __launch_bounds__(kThreads) void pers_fix_kernel(
   int32_t const* __restrict__ pers_v, ValT const* __restrict__ pers_p, int64_t n_pers,
   ValT const* __restrict__ pr_old, ValT* __restrict__ pr_new, ValT* __restrict__ x_next,
   ValT const* __restrict__ out_w, double const* __restrict__ scal, Ctrl* ctrl, double epsilon,
-  ValT alpha, ValT one_minus_alpha, int64_t vertex_first, double* __restrict__ partials)
+  ValT alpha, ValT one_minus_alpha, int64_t vertex_first, int32_t const* __restrict__ x_pos,
+  double* __restrict__ partials)
 {
   if (stop_check(ctrl, scal, epsilon, false)) return;
   ValT teleport = static_cast<ValT>(scal[0]) * alpha + one_minus_alpha;
@@ -758,7 +766,12 @@ __global__ __launch_bounds__(kThreads) void pers_fix_kernel(
       x = pr2 / ow;
     }
     pr_new[v]                = pr2;
-    x_next[vertex_first + v] = x;
+    if (x_pos) {
+      int32_t slot = x_pos[v];
+      if (slot >= 0) x_next[slot] = x;
+    } else {
+      x_next[vertex_first + v] = x;
+    }
   }
   write_partials(dangling, delta, partials);
 }
@@ -802,18 +815,21 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(double const* __rest
 template <typename ValT>
 __global__ __launch_bounds__(kThreads) void prep_kernel(ValT const* __restrict__ pr,
                                                         ValT const* __restrict__ out_w, int64_t n,
-                                                        int64_t vertex_first, ValT* __restrict__ x,
+                                                        int64_t vertex_first,
+                                                        int32_t const* __restrict__ x_pos,
+                                                        ValT* __restrict__ x,
                                                         double* __restrict__ partials)
 {
   double dangling = 0.0;
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n;
        v += (int64_t)gridDim.x * blockDim.x) {
     ValT p = pr[v], ow = out_w[v];
+    int64_t slot = x_pos ? static_cast<int64_t>(x_pos[v]) : vertex_first + v;
     if (ow == ValT(0)) {
       dangling += static_cast<double>(p);
-      x[vertex_first + v] = p;
-    } else {
-      x[vertex_first + v] = p / ow;
+      if (slot >= 0) x[slot] = p;
+    } else if (slot >= 0) {
+      x[slot] = p / ow;
     }
   }
   write_partials(dangling, 0.0, partials);
@@ -1087,7 +1103,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipStreamSynchronize(stream));
   int n_tiles     = static_cast<int>(n_tiles64);
   // windows of 2^20 slice-local source positions, so that a packed entry needs only 20 source bits
-  uint32_t max_local = xs_slice_local(static_cast<uint32_t>(g.num_global_vertices - 1), slice_shift) |
+  uint32_t max_local = xs_slice_local(static_cast<uint32_t>(g.minor_space() - 1), slice_shift) |
                        ((1u << slice_shift) - 1u);
   int n_win          = static_cast<int>(max_local >> kXsLowBits) + 1;
   int64_t n_units    = static_cast<int64_t>(n_tiles) * kXsSlices * n_win;
@@ -1104,7 +1120,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
                      offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(), slice_shift,
                      n_win, unit.as<int32_t>(), row_of_edge.as<int32_t>());
   CGA_HIP(hipGetLastError());
-  CompressedOut c = compress_coo_perm(stream, n_units, g.num_global_vertices, ne, unit.as<int32_t>(),
+  CompressedOut c = compress_coo_perm(stream, n_units, g.minor_space(), ne, unit.as<int32_t>(),
                                       g.indices + e0);
   unit.release();
   plan.xs_ent.alloc(static_cast<size_t>(ne + 4) * sizeof(uint32_t));
@@ -1193,6 +1209,8 @@ PullPlan& get_plan(Handle const& h, Graph& g)
 // per-source weight sums of this graph's edges, double[num_global_vertices]
 void compute_source_sums(hipStream_t stream, Graph const& g, double* sums)
 {
+  CGA_EXPECTS(g.x_pos == nullptr, CUGRAPH_INVALID_INPUT,
+              "source sums of a compact-source graph are indexed by slot: compute them from the edge list");
   CGA_HIP(hipMemsetAsync(sums, 0, static_cast<size_t>(g.num_global_vertices) * sizeof(double), stream));
   if (g.num_edges > 0) {
     if (g.weights && g.weight_type == FLOAT64)
@@ -1205,6 +1223,29 @@ void compute_source_sums(hipStream_t stream, Graph const& g, double* sums)
                          sums);
     CGA_HIP(hipGetLastError());
   }
+}
+
+// per-source weight sums (1 per edge when weights == nullptr) of a raw edge list
+void edgelist_source_sums(hipStream_t stream, ArrayView const& src, ArrayView const* weights,
+                          int64_t num_vertices, double* sums)
+{
+  CGA_HIP(hipMemsetAsync(sums, 0, static_cast<size_t>(num_vertices > 0 ? num_vertices : 1) * sizeof(double), stream));
+  int64_t ne = static_cast<int64_t>(src.size);
+  if (ne == 0) return;
+  DevBuf s32(static_cast<size_t>(ne) * 4);
+  int64_t smin = 0;
+  int64_t smax = narrow_ids(stream, src.data, src.type, src.size, s32.as<int32_t>(), &smin);
+  CGA_EXPECTS(smin >= 0 && smax < num_vertices, CUGRAPH_INVALID_INPUT,
+              "source ids outside [0, num_vertices)");
+  if (weights && weights->type == FLOAT64)
+    hipLaunchKernelGGL((source_sums_kernel<double>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                       s32.as<int32_t>(), static_cast<double const*>(weights->data), ne, sums);
+  else
+    hipLaunchKernelGGL((source_sums_kernel<float>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                       s32.as<int32_t>(), weights ? static_cast<float const*>(weights->data) : nullptr,
+                       ne, sums);
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
 }
 
 // ------------------------------------------------------------------ session
@@ -1308,6 +1349,7 @@ void session_setup(Session& s, PagerankArgs const& a)
                 "(see cugraph_amd.mg.partition_bounds)");
     s.x_len = chunk * P;
   }
+  if (g.x_pos) s.x_len = g.num_source_slots;  // compact source space: the caller sized and padded it
   for (int k = 0; k < 2; ++k) {
     s.pr[k].alloc(static_cast<size_t>(nl > 0 ? nl : 1) * vb);
     s.x[k].alloc(static_cast<size_t>(s.x_len > 0 ? s.x_len : 1) * vb);
@@ -1484,7 +1526,8 @@ void session_setup(Session& s, PagerankArgs const& a)
 
   // ---- x0 and the dangling mass of pr0
   hipLaunchKernelGGL((prep_kernel<ValT>), dim3(n_prep_blocks), dim3(kThreads), 0, stream,
-                     s.pr[0].as<ValT>(), s.out_w.as<ValT>(), nl, g.vertex_first, s.x[0].as<ValT>(),
+                     s.pr[0].as<ValT>(), s.out_w.as<ValT>(), nl, g.vertex_first, g.x_pos,
+                     s.x[0].as<ValT>(),
                      s.partials.as<double>());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, stream, s.partials.as<double>(),
                      n_prep_blocks, s.scal.as<double>(), s.ctrl.as<Ctrl>(), s.epsilon, 0);
@@ -1520,6 +1563,7 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.gather_mask  = gm ? static_cast<uint32_t>(std::strtoul(gm, nullptr, 0)) : 0xFFFFFFFFu;
   }
   a.vertex_first    = g.vertex_first;
+  a.x_pos           = g.x_pos;
   a.hub_items        = s.hub_items;
   a.n_hub_items      = s.n_hub_items;
   a.hub_item_partial = s.hub_item_partial.as<double>();
@@ -1568,7 +1612,7 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     hipLaunchKernelGGL((pers_fix_kernel<ValT>), dim3(s.n_pers_blocks), dim3(kThreads), 0, stream,
                        s.pers_v.as<int32_t>(), s.pers_p.as<ValT>(), s.n_pers, a.pr_old, a.pr_new,
                        a.x_next, a.out_w, a.scal, a.ctrl, a.epsilon, a.alpha, a.one_minus_alpha,
-                       a.vertex_first,
+                       a.vertex_first, a.x_pos,
                        s.partials.as<double>() +
                          2 * (s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks));
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, stream, s.partials.as<double>(),

@@ -28,6 +28,12 @@ old -> new table once and relabel their sources with it.  Ownership does not cha
 collectives stay what they were, and the local SpMV runs on contiguous degree buckets and XS
 tiles exactly like the single-GPU path.  Callers keep seeing the ids they passed in.
 
+Compact source space: only a vertex with out-edges is ever gathered (in an R-MAT scale-26 graph
+27 M of 67 M).  Each rank numbers its vertices that have out-edges 0..n_r-1 in row order; the
+vector the ranks all-gather has P chunks of max_r n_r slots, edge sources are stored as slots,
+and a rank writes vertex v's value to slot x_pos[v] (or nowhere).  The all-gather shrinks by the
+share of vertices without out-edges and the gathered vector gets denser.
+
 The local compute is reached through an *engine* object so that the driver logic (partition,
 routing, collectives, stop rule, result assembly) can be exercised at world_size 2 on CPU with
 a test double; the product engine is `HipEngine` and there is no other in this package.
@@ -117,13 +123,17 @@ class HipEngine:
                 free_view(v)
         return order, rank
 
-    def make_local_graph(self, src, dst, wgt, first, last, num_global):
+    def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
+                         x_pos=None):
         from . import pylibcugraph as plc
 
         return plc.MGGraph(self.handle, self.props, src, dst, wgt, vertex_first=first,
-                           vertex_last=last, num_global_vertices=num_global)
+                           vertex_last=last, num_global_vertices=num_global,
+                           num_source_slots=num_source_slots, x_pos=x_pos)
 
-    def source_weight_sums(self, graph, num_global):
+    def source_weight_sums(self, src, wgt, num_global):
+        """float64[num_global]: per-source sum of the weights (edge counts when wgt is None) of
+        this rank's edges."""
         import ctypes
 
         import torch
@@ -132,14 +142,16 @@ class HipEngine:
         from .pylibcugraph.utils import create_view_from_py_obj, free_view
 
         sums = torch.zeros(num_global, dtype=torch.float64, device="cuda")
-        view = create_view_from_py_obj(sums)
+        views = [create_view_from_py_obj(t) for t in (src.contiguous(),
+                                                     None if wgt is None else wgt.contiguous(), sums)]
         err = ctypes.c_void_p()
         try:
-            code = _capi.load().cugraph_amd_graph_source_weight_sums(
-                self.handle.c_resource_handle_ptr, graph.c_graph_ptr, view, ctypes.byref(err))
-            _capi.check(code, err, "cugraph_amd_graph_source_weight_sums")
+            code = _capi.load().cugraph_amd_edgelist_source_weight_sums(
+                self.handle.c_resource_handle_ptr, views[0], views[1], views[2], ctypes.byref(err))
+            _capi.check(code, err, "cugraph_amd_edgelist_source_weight_sums")
         finally:
-            free_view(view)
+            for v in views:
+                free_view(v)
         return sums
 
     def make_session(self, graph, **kw):
@@ -164,7 +176,8 @@ class MGPagerank:
         self.first, self.last, self.chunk = partition_bounds(self.num_vertices, world, rank)
         self.graph = None
         self.order = None  # int32[n_local]: internal position -> offset of the caller's id in the range
-        self.new_id = None  # [chunk * world]: caller's id -> internal id, every rank's range
+        self.rank_local = None  # int32[n_local]: offset of the caller's id in the range -> internal position
+        self.slot_chunk = 0  # slots per rank of the gathered vector (compact source space)
         self.out_w = None  # out-weight sums of the local vertices (float64), internal order
         self.value_dtype = None
         self.vertex_dtype = None
@@ -187,23 +200,38 @@ class MGPagerank:
         self.value_dtype = torch.float32 if wgt is None else wgt.dtype
         if world > 1:
             src, dst, wgt = shuffle_edges_to_owner(src, dst, wgt, self.chunk, world, group)
-        # descending in-degree inside the owned range; one all-gather of the old -> new table
-        self.order, rank_local = engine.degree_order(dst, self.first, self.last)
-        self.new_id = torch.zeros(self.chunk * world, dtype=src.dtype, device=src.device)
-        self.new_id[self.first:self.last] = rank_local.to(src.dtype) + self.first
-        del rank_local
+        # out-edge counts and out-weight sums per source, over all ranks
+        counts = engine.source_weight_sums(src, None, self.num_vertices)
+        sums = counts if wgt is None else engine.source_weight_sums(src, wgt, self.num_vertices)
         if world > 1:
-            all_gather_in_place(self.new_id, self.chunk, rank, world, group)
-        src = self.new_id[src.long()] if src.dtype != torch.int32 else self.new_id[src]
-        dst = self.new_id[dst.long()] if dst.dtype != torch.int32 else self.new_id[dst]
-        self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last,
-                                             self.num_vertices)
-        del src, dst, wgt
-        sums = engine.source_weight_sums(self.graph, self.num_vertices)
+            dist.all_reduce(counts, group=group)
+            if wgt is not None:
+                dist.all_reduce(sums, group=group)
+        # rows: descending in-degree inside the owned range
+        self.order, self.rank_local = engine.degree_order(dst, self.first, self.last)
+        order = self.order.long()
+        # slots: this rank's vertices with out-edges, numbered in row order
+        active = counts[self.first:self.last][order] > 0
+        n_active = torch.count_nonzero(active).reshape(1).to(torch.int64)
         if world > 1:
-            dist.all_reduce(sums, group=group)
-        self.out_w = sums[self.first:self.last].clone()
-        del sums
+            dist.all_reduce(n_active, op=dist.ReduceOp.MAX, group=group)
+        self.slot_chunk = max(int(n_active.item()), 1)
+        x_pos = torch.where(active, torch.cumsum(active, 0) - 1 + rank * self.slot_chunk,
+                            torch.full_like(order, -1)).to(torch.int32)
+        del active
+        # caller's id -> slot, for every rank's range: one all-gather of the per-rank tables
+        slot_of = torch.full((self.chunk * world,), -1, dtype=torch.int32, device=src.device)
+        slot_of[self.first + order] = x_pos
+        if world > 1:
+            all_gather_in_place(slot_of, self.chunk, rank, world, group)
+        src = slot_of[src.long()].to(self.vertex_dtype)
+        dst = (self.rank_local[(dst - self.first).long()] + self.first).to(self.vertex_dtype)
+        del slot_of
+        self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last, self.num_vertices,
+                                             num_source_slots=self.slot_chunk * world, x_pos=x_pos)
+        del src, dst, wgt, x_pos
+        self.out_w = sums[self.first:self.last][order].clone()  # internal (row) order
+        del sums, counts
         self.t_build = time.perf_counter() - t0
         return self
 
@@ -239,7 +267,7 @@ class MGPagerank:
         v = torch.as_tensor(vertices, device=self.engine.device).to(self.vertex_dtype)
         x = torch.as_tensor(values, device=self.engine.device).to(torch.float64)
         keep = (v >= self.first) & (v < self.last)
-        v = self.new_id[v[keep].long()].to(self.vertex_dtype)
+        v = (self.rank_local[(v[keep] - self.first).long()] + self.first).to(self.vertex_dtype)
         return v.contiguous(), (x[keep] / scale).to(self.value_dtype).contiguous()
 
     def session(self, *, alpha=0.85, epsilon=1e-6, nstart=None, personalization=None):
@@ -269,7 +297,7 @@ class MGPagerank:
         if self.world == 1 and not self.always_exchange:
             return
         x_full, scal = sess.inner.exchange_buffers()
-        all_gather_in_place(x_full, self.chunk, self.rank, self.world, self.group)
+        all_gather_in_place(x_full, self.slot_chunk, self.rank, self.world, self.group)
         _dist().all_reduce(scal, group=self.group)
 
     def iterate(self, sess, n=1):

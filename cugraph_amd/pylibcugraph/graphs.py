@@ -107,20 +107,31 @@ class MGGraph(_GPUGraph):
     """
 
     def __init__(self, resource_handle, graph_properties, src_array, dst_array, weight_array=None,
-                 *, vertex_first, vertex_last, num_global_vertices):
+                 *, vertex_first, vertex_last, num_global_vertices, num_source_slots=None,
+                 x_pos=None):
+        """num_source_slots / x_pos: compact source space (src_array then holds slots of the
+        gathered vector, see cugraph_amd_graph_create_local_compact)."""
         assert_CAI_type(src_array, "src_array")
         assert_CAI_type(dst_array, "dst_array")
         assert_CAI_type(weight_array, "weight_array", True)
+        assert_CAI_type(x_pos, "x_pos", True)
         lib = _capi.load()
-        views = [create_view_from_py_obj(a) for a in (src_array, dst_array, weight_array)]
+        views = [create_view_from_py_obj(a) for a in (src_array, dst_array, weight_array, x_pos)]
         graph = ctypes.c_void_p()
         err = ctypes.c_void_p()
         try:
-            code = lib.cugraph_amd_graph_create_local(
-                resource_handle.c_resource_handle_ptr,
-                ctypes.byref(graph_properties.c_graph_properties), views[0], views[1], views[2],
-                int(vertex_first), int(vertex_last), int(num_global_vertices),
-                ctypes.byref(graph), ctypes.byref(err))
+            if num_source_slots is None:
+                code = lib.cugraph_amd_graph_create_local(
+                    resource_handle.c_resource_handle_ptr,
+                    ctypes.byref(graph_properties.c_graph_properties), views[0], views[1], views[2],
+                    int(vertex_first), int(vertex_last), int(num_global_vertices),
+                    ctypes.byref(graph), ctypes.byref(err))
+            else:
+                code = lib.cugraph_amd_graph_create_local_compact(
+                    resource_handle.c_resource_handle_ptr,
+                    ctypes.byref(graph_properties.c_graph_properties), views[0], views[1], views[2],
+                    int(vertex_first), int(vertex_last), int(num_global_vertices),
+                    int(num_source_slots), views[3], ctypes.byref(graph), ctypes.byref(err))
             _capi.check(code, err, "cugraph_amd_graph_create_local()")
         finally:
             for v in views:

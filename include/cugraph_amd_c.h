@@ -251,6 +251,30 @@ cugraph_error_code_t cugraph_amd_graph_create_local(
   int64_t vertex_last, int64_t num_global_vertices, cugraph_graph_t** graph,
   cugraph_error_t** error);
 
+/* As cugraph_amd_graph_create_local, with a COMPACT SOURCE SPACE: `src_slots` holds, instead of
+ * vertex ids, slots of the vector the ranks all-gather, in [0, num_source_slots); x_pos (INT32,
+ * one per local vertex, in the order of the local destination ids) is the slot this rank writes
+ * each of its vertices' value to, or -1 for a vertex no edge leaves (nobody ever gathers it).
+ * The multi-GPU driver numbers only vertices WITH out-edges (27 M of the 67 M of an R-MAT
+ * scale-26 graph), which cuts the per-iteration all-gather to that fraction.  num_source_slots
+ * is P equal per-rank chunks; rank r's slots are chunk r. */
+cugraph_error_code_t cugraph_amd_graph_create_local_compact(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src_slots,
+  const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights, int64_t vertex_first,
+  int64_t vertex_last, int64_t num_global_vertices, int64_t num_source_slots,
+  const cugraph_type_erased_device_array_view_t* x_pos, cugraph_graph_t** graph,
+  cugraph_error_t** error);
+
+/* sums[v] (FLOAT64, one per vertex id in [0, size of sums)) = sum of the weights (1 per edge when
+ * weights is NULL) of the edges of a raw edge list whose source is v.  The multi-GPU driver
+ * all-reduces them: out-weight sums, and out-edge counts for the compact source space. */
+cugraph_error_code_t cugraph_amd_edgelist_source_weight_sums(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* weights,
+  cugraph_type_erased_device_array_view_t* sums, cugraph_error_t** error);
+
 /* Descending in-degree order of the destinations [vertex_first, vertex_last) a rank owns, from
  * the destination ids (INT32/INT64, global) of the edges routed to it:
  *   order[new] = old - vertex_first,  rank[old - vertex_first] = new   (INT32 views, stable).

@@ -11,8 +11,10 @@ import torch
 
 
 class _Graph:
-    def __init__(self, src, dst, wgt, first, last, num_global):
+    def __init__(self, src, dst, wgt, first, last, num_global, num_source_slots, x_pos):
         self.first, self.last, self.num_global = first, last, num_global
+        self.slots = num_source_slots
+        self.x_pos = x_pos.numpy().astype(np.int64)  # slot of each local row, -1: never gathered
         self.src = src.numpy().astype(np.int64)
         self.dst = dst.numpy().astype(np.int64)
         self.wgt = None if wgt is None else wgt.numpy().astype(np.float64)
@@ -26,6 +28,10 @@ class _Session:
         nl = g.last - g.first
         chunk = (g.num_global + world - 1) // world
         assert g.first == min(rank * chunk, g.num_global)
+        assert g.slots % world == 0 and np.all(g.src < g.slots)
+        mine = g.x_pos[g.x_pos >= 0]
+        assert np.all((mine >= rank * (g.slots // world)) & (mine < (rank + 1) * (g.slots // world)))
+        self.wr = g.x_pos >= 0
         self.out_w = np.zeros(nl)
         self.out_w[out_w_v.numpy() - g.first] = out_w.numpy()
         self.pr = np.full(nl, 1.0 / g.num_global)
@@ -36,12 +42,12 @@ class _Session:
         if pers_v is not None:
             self.pers = np.zeros(nl)
             np.add.at(self.pers, pers_v.numpy() - g.first, pers_x.numpy())  # already normalised
-        self.x = [torch.zeros(chunk * world, dtype=torch.float64) for _ in range(2)]
+        self.x = [torch.zeros(g.slots, dtype=torch.float64) for _ in range(2)]
         self.scal = torch.zeros(2, dtype=torch.float64)
         self.enqueued, self.iters, self.done = 0, 0, False
         dang = self.out_w == 0
         xs = np.where(dang, self.pr, self.pr / np.where(dang, 1.0, self.out_w))
-        self.x[0][g.first:g.last] = torch.from_numpy(xs)
+        self.x[0][g.x_pos[self.wr]] = torch.from_numpy(xs[self.wr])
         self.scal[0] = float(self.pr[dang].sum())
         self.scal[1] = 1e300
 
@@ -67,7 +73,7 @@ class _Session:
             self.scal[1] = float(np.abs(pr - self.pr).sum())
             self.scal[0] = float(pr[dang].sum())
             xs = np.where(dang, pr, pr / np.where(dang, 1.0, self.out_w))
-            self.x[nxt][g.first:g.last] = torch.from_numpy(xs)
+            self.x[nxt][g.x_pos[self.wr]] = torch.from_numpy(xs[self.wr])
             self.pr = pr
             self.iters += 1
 
@@ -96,12 +102,14 @@ class OracleEngine:
         rank[order] = np.arange(len(order), dtype=np.int32)
         return torch.from_numpy(order), torch.from_numpy(rank)
 
-    def make_local_graph(self, src, dst, wgt, first, last, num_global):
-        return _Graph(src, dst, wgt, first, last, num_global)
+    def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
+                         x_pos=None):
+        return _Graph(src, dst, wgt, first, last, num_global, num_source_slots, x_pos)
 
-    def source_weight_sums(self, graph, num_global):
-        w = np.ones(len(graph.src)) if graph.wgt is None else graph.wgt
-        return torch.from_numpy(np.bincount(graph.src, weights=w, minlength=num_global))
+    def source_weight_sums(self, src, wgt, num_global):
+        w = np.ones(len(src)) if wgt is None else wgt.numpy().astype(np.float64)
+        return torch.from_numpy(np.bincount(src.numpy().astype(np.int64), weights=w,
+                                            minlength=num_global))
 
     def make_session(self, graph, *, alpha, epsilon, precomputed_vertex_out_weight_vertices,
                      precomputed_vertex_out_weight_sums, initial_guess_vertices=None,

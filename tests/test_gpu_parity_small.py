@@ -291,7 +291,8 @@ def test_partitioned_sessions_emulated_ranks(world, weighted, xs_tiles, monkeypa
     props = plc.GraphProperties(is_multigraph=True)
     chunk = (nv + world - 1) // world
     engines, orders, ranks_l, bounds = [], [], [], []
-    new_id = torch.zeros(chunk * world, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(nv, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(nv, dtype=torch.float64, device="cuda")
     for r in range(world):
         first, last, _ = mg.partition_bounds(nv, world, r)
         eng = mg.HipEngine(plc.ResourceHandle(rank=r, comm_size=world), props)
@@ -299,14 +300,28 @@ def test_partitioned_sessions_emulated_ranks(world, weighted, xs_tiles, monkeypa
         order, rank_l = eng.degree_order(to_dev(dst[sel]), first, last)
         deg = np.bincount(dst[sel] - first, minlength=last - first)
         assert np.array_equal(order.cpu().numpy(), np.argsort(-deg, kind="stable"))
-        new_id[first:last] = rank_l + first
-        engines.append(eng), orders.append(order), bounds.append((first, last, sel))
-    graphs, sums = [], torch.zeros(nv, dtype=torch.float64, device="cuda")
+        counts += eng.source_weight_sums(to_dev(src[sel]), None, nv)
+        sums += eng.source_weight_sums(to_dev(src[sel]), None if wgt is None else to_dev(wgt[sel]), nv)
+        engines.append(eng), orders.append(order), ranks_l.append(rank_l), bounds.append((first, last, sel))
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(src, minlength=nv))
+    # compact source space: vertices with out-edges, numbered per rank in row order
+    actives = [counts[b[0]:b[1]][o.long()] > 0 for b, o in zip(bounds, orders)]
+    slot_chunk = max(int(a.sum()) for a in actives)
+    slot_of = torch.full((nv,), -1, dtype=torch.int32, device="cuda")
+    x_poss = []
+    for r in range(world):
+        a = actives[r]
+        x_pos = torch.where(a, torch.cumsum(a, 0) - 1 + r * slot_chunk,
+                            torch.full_like(orders[r].long(), -1)).to(torch.int32)
+        slot_of[bounds[r][0] + orders[r].long()] = x_pos
+        x_poss.append(x_pos)
+    graphs = []
     for r in range(world):
         first, last, sel = bounds[r]
-        g = engines[r].make_local_graph(new_id[to_dev(src[sel]).long()], new_id[to_dev(dst[sel]).long()],
-                                        None if wgt is None else to_dev(wgt[sel]), first, last, nv)
-        sums += engines[r].source_weight_sums(g, nv)
+        g = engines[r].make_local_graph(
+            slot_of[to_dev(src[sel]).long()], ranks_l[r][(to_dev(dst[sel]) - first).long()] + first,
+            None if wgt is None else to_dev(wgt[sel]), first, last, nv,
+            num_source_slots=slot_chunk * world, x_pos=x_poss[r])
         graphs.append(g)
     eps = nv * 1e-8
     sessions = []
@@ -315,15 +330,15 @@ def test_partitioned_sessions_emulated_ranks(world, weighted, xs_tiles, monkeypa
         ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
         sessions.append(engines[r].make_session(
             graphs[r], alpha=0.85, epsilon=eps, precomputed_vertex_out_weight_vertices=ids,
-            precomputed_vertex_out_weight_sums=sums[first:last].to(torch.float32)))
+            precomputed_vertex_out_weight_sums=sums[first:last][orders[r].long()].to(torch.float32)))
 
     def exchange():
         bufs = [s.exchange_buffers() for s in sessions]
         x = torch.zeros_like(bufs[0][0])
         scal = torch.zeros(2, dtype=torch.float64, device="cuda")
         for r, (xf, sc) in enumerate(bufs):
-            first, last, _ = bounds[r]
-            x[first:last] = xf[first:last]
+            assert xf.numel() == slot_chunk * world
+            x[r * slot_chunk:(r + 1) * slot_chunk] = xf[r * slot_chunk:(r + 1) * slot_chunk]
             scal += sc
         for xf, sc in bufs:
             xf.copy_(x), sc.copy_(scal)
