@@ -44,13 +44,16 @@ def nx_pagerank(num_vertices, src, dst, weights=None, *, alpha=0.85, tol=1e-6, m
 
 
 def scipy_pagerank(num_vertices, src, dst, weights=None, *, alpha=0.85, tol=1e-6, max_iter=100,
-                   nstart=None, personalization=None, return_info=False):
+                   nstart=None, personalization=None, return_info=False, timings=None):
     """_pagerank_scipy's loop on raw arrays.  nstart / personalization are dense vectors or None.
 
     Raises RuntimeError after max_iter iterations without err < N*tol (NetworkX raises
     PowerIterationFailedConvergence there)."""
+    import time
+
     import scipy.sparse as sp
 
+    t_start = time.perf_counter()
     N = int(num_vertices)
     src = np.asarray(src)
     dst = np.asarray(dst)
@@ -71,10 +74,16 @@ def scipy_pagerank(num_vertices, src, dst, weights=None, *, alpha=0.85, tol=1e-6
         p = p / p.sum()
     is_dangling = np.where(S == 0)[0]
     AT = sp.csr_array(A.T)  # x @ A == A.T @ x; csr mat-vec is the fast path
+    t_loop = time.perf_counter()
+    if timings is not None:
+        timings["build_s"] = t_loop - t_start
     for it in range(max_iter):
         xlast = x
         x = alpha * (AT @ x + x[is_dangling].sum() * p) + (1 - alpha) * p
         err = np.absolute(x - xlast).sum()
+        if timings is not None:
+            timings["loop_s"] = time.perf_counter() - t_loop
+            timings["iterations"] = it + 1
         if err < N * tol:
             return (x, it + 1) if return_info else x
     raise RuntimeError(f"power iteration failed to converge in {max_iter} iterations")
