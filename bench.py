@@ -159,9 +159,9 @@ def other_cpu_baselines(args, handle):
 
 
 def pmc_traffic(scale, ef, n_gpus):
-    """HBM bytes per spmv_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
+    """HBM bytes per xs_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
     None when they do not describe this workload.  bench.py cannot run under the profiler itself."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_spmv.json")
+    path = os.path.join(ROOT, "profiles", "r1_pmc_xs.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -264,17 +264,18 @@ def main():
     n_probe = min(args.steps, 10)
     iter_ms, kern_ms = inner.timed_iterate(n_probe) if not use_mg else mg.timed_iterate(sess, n_probe)
     kern_avg_ms = float(kern_ms.mean())
-    bytes_per_launch = info["spmv_kernel_bytes"]  # this rank's share for N > 1
+    bytes_per_launch = info["dominant_kernel_bytes"]  # this rank's share for N > 1
     achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": "spmv_kernel",
+        "kernel": "xs_kernel" if info["mid_degree_vertices"] and os.environ.get("CUGRAPH_AMD_XS") != "0"
+                  else "spmv_kernel",
         "achieved": achieved,
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": pmc_traffic(scale, ef, world),
-        "traffic_source": "profiles/r1_pmc_spmv.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command)",
+        "traffic_source": "profiles/r1_pmc_xs.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command)",
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "kernel_ms_avg": kern_avg_ms,
         "iteration_ms_event_avg": float(iter_ms.mean()),

@@ -45,12 +45,12 @@ constexpr int64_t kHubChunk = 32768;  // edges of one hub work item (longer colu
 // XS ("XCD-sliced, source-sorted") tiles for the mid-degree rows: see the comment at xs_bucket
 constexpr int kXsSlices       = 8;      // one slice of the source ids per XCD
 constexpr int64_t kXsTileEdges = 1 << 23;  // a tile is a run of rows holding about this many edges,
-constexpr int kXsMaxRows      = 4096;     // but never more than this many rows (LDS accumulators)
+constexpr int kXsEntriesPerLane = 8;   // gathers a lane keeps in flight per pass
+constexpr int kXsRowBits      = 12;       // a tile never has more than 2^12 rows (32 KiB of fp64 LDS accumulators)
 constexpr int kXsMinDegree    = 4;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
-constexpr int kXsRowBits      = 12;       // log2(kXsMaxRows): row field of a packed entry
-constexpr int kXsLowBits      = 32 - kXsRowBits;  // source bits an entry carries; the rest is its window
+// a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile
 
 // slice of a source id: interleaved in granules of 2^shift ids (default 128 ids = four 128-B lines)
 __host__ __device__ inline uint32_t xs_slice_of(uint32_t src, int shift)
@@ -74,8 +74,9 @@ struct XsArgs {
   uint32_t const* ent;
   ValT const* w;             // [n_edges + 4] or nullptr
   int64_t const* unit_off;   // [n_tiles * 8 * n_win + 1]
-  int n_win;                 // windows of 2^20 slice-local positions per slice
+  int n_win;                 // windows of 2^(32 - row_bits) slice-local positions per slice
   int slice_shift;
+  int row_bits;
   int32_t const* tile_row;   // [n_tiles + 1] first row of each tile, relative to row_first
   ValT* partial;             // [8][n_rows] per-slice partial sums
   int* counters;             // [8] next tile of each slice's queue
@@ -83,8 +84,6 @@ struct XsArgs {
   int n_tiles;
   int block_begin, n_blocks;
   int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
-  int dedupe;
-  uint32_t fake_hot;  // timing aid: sources below this slice-local position are not gathered
 };
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
@@ -424,12 +423,18 @@ __device__ inline void stream_load4(uint32_t const* p, uint32_t* r)
 // (slice, row); xs_finish_kernel adds the 8 partials and runs the epilogue.  Workgroups pull
 // tiles from the queue of the XCD they run on (HW_REG_XCC_ID) and steal from the other queues
 // when theirs is empty, so the result never depends on where a workgroup was placed.
-template <typename OffT, typename ValT, bool WEIGHTED>
-__device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
+template <typename OffT, typename ValT, bool WEIGHTED, int THREADS, int ROWBITS>
+__global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
 {
   using XsAcc = double;
-  __shared__ XsAcc acc[kXsMaxRows];
+  constexpr int kLowBits       = 32 - ROWBITS;
+  constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
+  constexpr int EPL            = kXsEntriesPerLane;
+  constexpr uint32_t kPass     = THREADS * EPL;  // entries per pass of the workgroup
+  extern __shared__ double xs_lds[];
+  XsAcc* acc = xs_lds;  // [2^ROWBITS]
   __shared__ int s_tile;
+  if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
   XsArgs<ValT> const& xs = a.xs;
   int const tid = threadIdx.x;
   int const my  = xs.affinity_mode == 0   ? static_cast<int>(xcc_id() & (kXsSlices - 1))
@@ -445,7 +450,7 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
       if (t >= xs.n_tiles) break;
       int const row0 = xs.tile_row[t];
       int const rows = xs.tile_row[t + 1] - row0;
-      for (int i = tid; i < rows; i += kThreads) acc[i] = 0;
+      for (int i = tid; i < rows; i += THREADS) acc[i] = 0;
       __syncthreads();
       // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
       // so every lane keeps the 4 row sums in registers and the block reduces them at the end
@@ -473,56 +478,56 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
         return c;
       };
       uint32_t const low_mask = (1u << shift) - 1u;
-      // one pass of the workgroup over 2048 entries (8 per lane).  FAST: all of them exist and
+      // one pass of the workgroup over THREADS * EPL entries (EPL per lane).  FAST: all of them exist and
       // lie in one window (decided on uniform values), so no per-entry predicates or windows.
       auto pass = [&](auto fast_tag, uint32_t pb, uint32_t win_uniform) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        // entry e of lane tid: pb + e * 256 + tid, so that the 64 lanes of one gather instruction
+        // entry e of lane tid: pb + e * THREADS + tid, so that the 64 lanes of one gather instruction
         // hold 64 CONSECUTIVE entries (ascending sources: few cache lines per instruction)
         uint32_t const pos = pb + static_cast<uint32_t>(tid);
-        uint32_t en[8];
-        ValT w[8];
-        bool p[8];
+        uint32_t en[EPL];
+        ValT w[EPL];
+        bool p[EPL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          uint32_t q = pos + e * kThreads;
+        for (int e = 0; e < EPL; ++e) {
+          uint32_t q = pos + e * THREADS;
           p[e]       = FAST || (q >= rbeg && q < rend);
           en[e]      = p[e] ? __builtin_nontemporal_load(xs.ent + abeg + q) : 0u;
           if constexpr (WEIGHTED) w[e] = p[e] ? __builtin_nontemporal_load(xs.w + abeg + q) : ValT(0);
         }
-        uint32_t loc[8];  // slice-local source position
+        uint32_t loc[EPL];  // slice-local source position
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          uint32_t wn = FAST ? win_uniform : window_of(pos + e * kThreads);
-          loc[e]      = (wn << kXsLowBits) | (en[e] >> kXsRowBits);
+        for (int e = 0; e < EPL; ++e) {
+          uint32_t wn = FAST ? win_uniform : window_of(pos + e * THREADS);
+          loc[e]      = (wn << kLowBits) | (en[e] >> ROWBITS);
         }
-        ValT xv[8];
+        ValT xv[EPL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < EPL; ++e) {
           uint32_t gi = ((loc[e] & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc[e] & low_mask);
-          xv[e]       = (p[e] && loc[e] >= xs.fake_hot) ? a.x_cur[gi & a.gather_mask] : ValT(0);
+          xv[e]       = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
         }
         if constexpr (WEIGHTED) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) xv[e] *= w[e];
+          for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
         }
         if (few) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
+          for (int e = 0; e < EPL; ++e) {
             double v    = p[e] ? static_cast<double>(xv[e]) : 0.0;
-            uint32_t rl = en[e] & (kXsMaxRows - 1);
+            uint32_t rl = en[e] & kRowMask;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) racc[rr] += rl == (uint32_t)rr ? v : 0.0;
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (p[e]) atomicAdd(&acc[en[e] & (kXsMaxRows - 1)], static_cast<XsAcc>(xv[e]));
+          for (int e = 0; e < EPL; ++e)
+            if (p[e]) atomicAdd(&acc[en[e] & kRowMask], static_cast<XsAcc>(xv[e]));
         }
       };
-      for (uint32_t pb = 0; pb < rend; pb += 2 * kThreads * 4) {
-        uint32_t const w_lo = window_of(pb), w_hi = window_of(pb + 2 * kThreads * 4 - 1);
-        if (pb >= rbeg && pb + 2 * kThreads * 4 <= rend && w_lo == w_hi)
+      for (uint32_t pb = 0; pb < rend; pb += kPass) {
+        uint32_t const w_lo = window_of(pb), w_hi = window_of(pb + kPass - 1);
+        if (pb >= rbeg && pb + kPass <= rend && w_lo == w_hi)
           pass(std::true_type{}, pb, w_lo);
         else
           pass(std::false_type{}, pb, 0u);
@@ -536,7 +541,7 @@ __device__ inline void xs_bucket(IterArgs<OffT, ValT> const& a)
       }
       __syncthreads();
       ValT* out = xs.partial + (int64_t)k * xs.n_rows + row0;
-      for (int i = tid; i < rows; i += kThreads)
+      for (int i = tid; i < rows; i += THREADS)
         __builtin_nontemporal_store(static_cast<ValT>(acc[i]), out + i);
       __syncthreads();
     }
@@ -549,11 +554,9 @@ __global__ __launch_bounds__(kThreads) void spmv_kernel(IterArgs<OffT, ValT> a)
   if (stop_check(a.ctrl, a.scal, a.epsilon, true)) return;
   Epilogue<OffT, ValT> ep(a);
   int blk = blockIdx.x;
-  // order in the launch: hub items, XS tiles, wave64, 16-lane, thread per vertex, isolated
+  // order in the launch: hub items, wave64, 16-lane, thread per vertex, isolated (XS tiles: xs_kernel)
   if (blk < a.buckets[0].block_begin + a.buckets[0].n_blocks) {
     hub_bucket<OffT, ValT, WEIGHTED>(a, a.buckets[0]);
-  } else if (blk < a.xs.block_begin + a.xs.n_blocks) {
-    xs_bucket<OffT, ValT, WEIGHTED>(a);
   } else if (blk < a.buckets[1].block_begin + a.buckets[1].n_blocks) {
     group_bucket<64, OffT, ValT, WEIGHTED>(a, a.buckets[1], ep);
   } else if (blk < a.buckets[2].block_begin + a.buckets[2].n_blocks) {
@@ -608,7 +611,7 @@ template <typename OffT>
 __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const* __restrict__ indices,
                                 int64_t row_first, int64_t n_rows, int64_t e0,
                                 int32_t const* __restrict__ tile_of_row, int slice_shift, int n_win,
-                                int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge)
+                                int row_bits, int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge)
 {
   constexpr int G = 16;
   int lane        = threadIdx.x & (G - 1);
@@ -621,7 +624,7 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
     for (int64_t j = beg + lane; j < end; j += G) {
       uint32_t src   = static_cast<uint32_t>(indices[j]);
       uint32_t slice = xs_slice_of(src, slice_shift);
-      uint32_t win   = xs_slice_local(src, slice_shift) >> kXsLowBits;
+      uint32_t win   = xs_slice_local(src, slice_shift) >> (32 - row_bits);
       unit[j - e0]   = (t * kXsSlices + static_cast<int32_t>(slice)) * n_win + static_cast<int32_t>(win);
       row_of_edge[j - e0] = static_cast<int32_t>(i);
     }
@@ -629,19 +632,19 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
 }
 
 // A tile is a run of rows: a new one starts whenever a row's first edge falls into a new window
-// of kXsTileEdges edges, and at every kXsMaxRows-th row.  So a tile has at most kXsMaxRows rows
+// of kXsTileEdges edges, and at every 2^row_bits-th row.  So a tile has at most 2^row_bits rows
 // and about kXsTileEdges edges (64 rows of 16K edges, or 4096 rows of 16); a longer column simply
 // makes its tile longer.  flags mark the first row of each tile; a scan numbers the tiles.
 template <typename OffT>
 __global__ void xs_break_flags_kernel(OffT const* __restrict__ offsets, int64_t row_first,
-                                      int64_t n_rows, int64_t e0, int64_t tile_edges,
+                                      int64_t n_rows, int64_t e0, int64_t tile_edges, int64_t max_rows,
                                       unsigned int* __restrict__ flags)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
     int64_t w  = (static_cast<int64_t>(offsets[row_first + i]) - e0) / tile_edges;
     int64_t wp = i == 0 ? -1 : (static_cast<int64_t>(offsets[row_first + i - 1]) - e0) / tile_edges;
-    flags[i]   = (w != wp || (i % kXsMaxRows) == 0) ? 1u : 0u;
+    flags[i]   = (w != wp || (i % max_rows) == 0) ? 1u : 0u;
   }
 }
 
@@ -668,7 +671,7 @@ __global__ void xs_payload_kernel(int32_t const* __restrict__ tile_of_row, int64
                                   int32_t const* __restrict__ tile_row,
                                   ValT const* __restrict__ w_in, UOffT const* __restrict__ unit_off_in,
                                   int64_t n_units, int32_t const* __restrict__ src_sorted,
-                                  int slice_shift, uint32_t* __restrict__ ent,
+                                  int slice_shift, int row_bits, uint32_t* __restrict__ ent,
                                   ValT* __restrict__ w_out, int64_t* __restrict__ unit_off_out)
 {
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_edges;
@@ -677,8 +680,8 @@ __global__ void xs_payload_kernel(int32_t const* __restrict__ tile_of_row, int64
     int32_t r  = row_of_edge[e];
     uint32_t rl  = static_cast<uint32_t>(r - tile_row[tile_of_row[r]]);
     uint32_t low = xs_slice_local(static_cast<uint32_t>(src_sorted[k]), slice_shift) &
-                   ((1u << kXsLowBits) - 1u);
-    ent[k]       = (low << kXsRowBits) | rl;
+                   ((1u << (32 - row_bits)) - 1u);
+    ent[k]       = (low << row_bits) | rl;
     if (w_in) w_out[k] = w_in[e0 + e];
   }
   for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u <= n_units;
@@ -688,13 +691,13 @@ __global__ void xs_payload_kernel(int32_t const* __restrict__ tile_of_row, int64
 
 // debug aid (CUGRAPH_AMD_XS_VERIFY=1): entries of a unit must ascend by source
 __global__ void xs_verify_kernel(uint32_t const* __restrict__ ent, int64_t const* __restrict__ unit_off,
-                                 int64_t n_units, unsigned long long* __restrict__ out)
+                                 int64_t n_units, int row_bits, unsigned long long* __restrict__ out)
 {
   for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
     int64_t b = unit_off[u], e = unit_off[u + 1];
     unsigned long long bad = 0, same = 0;
     for (int64_t k = b + 1 + threadIdx.x; k < e; k += blockDim.x) {
-      uint32_t a0 = ent[k - 1] >> kXsRowBits, a1 = ent[k] >> kXsRowBits;
+      uint32_t a0 = ent[k - 1] >> row_bits, a1 = ent[k] >> row_bits;
       bad += a1 < a0;
       same += a1 == a0;
     }
@@ -1004,7 +1007,7 @@ struct PullPlan {
   bool xs_on{false};
   int64_t xs_row_first{0}, xs_n_rows{0}, xs_n_edges{0};
   int xs_n_tiles{0};
-  int xs_n_win{1}, xs_slice_shift{7};
+  int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
   DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
@@ -1093,19 +1096,23 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int64_t tile_edges  = te_env ? std::atoll(te_env) : kXsTileEdges;
   char const* sh_env  = std::getenv("CUGRAPH_AMD_XS_SLICE_SHIFT");
   int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
+  // 13 / 14 (512- / 1024-thread workgroups, 64 / 128 KiB of accumulators, tiles of up to 8192 /
+  // 16384 rows) were measured at scale 26: 3.8 / 7.0 ms against 2.3 ms for 12 -- kept at 12
+  int const row_bits  = kXsRowBits;
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
-                     offsets, row_first, n_rows, e0, tile_edges, flags.as<unsigned int>());
+                     offsets, row_first, n_rows, e0, tile_edges, int64_t(1) << row_bits,
+                     flags.as<unsigned int>());
   exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n_rows, pos.as<int64_t>());
   int64_t n_tiles64 = 0;
   CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
   int n_tiles     = static_cast<int>(n_tiles64);
-  // windows of 2^20 slice-local source positions, so that a packed entry needs only 20 source bits
+  // windows of 2^(32 - row_bits) slice-local source positions: a packed entry carries only those bits
   uint32_t max_local = xs_slice_local(static_cast<uint32_t>(g.minor_space() - 1), slice_shift) |
                        ((1u << slice_shift) - 1u);
-  int n_win          = static_cast<int>(max_local >> kXsLowBits) + 1;
+  int n_win          = static_cast<int>(max_local >> (32 - row_bits)) + 1;
   int64_t n_units    = static_cast<int64_t>(n_tiles) * kXsSlices * n_win;
   if (n_units >= 0x7fffffffLL) return;
   plan.xs_tile_row.alloc(static_cast<size_t>(n_tiles + 1) * 4);
@@ -1118,7 +1125,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   DevBuf unit(static_cast<size_t>(ne) * 4), row_of_edge(static_cast<size_t>(ne) * 4);
   hipLaunchKernelGGL((xs_label_kernel<OffT>), dim3(grid_for(n_rows * 16)), dim3(kThreads), 0, stream,
                      offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(), slice_shift,
-                     n_win, unit.as<int32_t>(), row_of_edge.as<int32_t>());
+                     n_win, row_bits, unit.as<int32_t>(), row_of_edge.as<int32_t>());
   CGA_HIP(hipGetLastError());
   CompressedOut c = compress_coo_perm(stream, n_units, g.minor_space(), ne, unit.as<int32_t>(),
                                       g.indices + e0);
@@ -1136,7 +1143,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
                        stream, tile_of_row.as<int32_t>(), e0, ne, c.perm.as<uint32_t>(),
                        row_of_edge.as<int32_t>(), plan.xs_tile_row.as<int32_t>(),
                        static_cast<ValT const*>(g.weights), c.offsets.as<UOffT>(), n_units,
-                       c.indices.as<int32_t>(), slice_shift, plan.xs_ent.as<uint32_t>(),
+                       c.indices.as<int32_t>(), slice_shift, row_bits, plan.xs_ent.as<uint32_t>(),
                        plan.xs_w.as<ValT>(), plan.xs_unit_off.as<int64_t>());
   };
   if (c.off64)
@@ -1149,7 +1156,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     DevBuf out(24);
     CGA_HIP(hipMemsetAsync(out.p, 0, 24, stream));
     hipLaunchKernelGGL(xs_verify_kernel, dim3(4096), dim3(kThreads), 0, stream,
-                       plan.xs_ent.as<uint32_t>(), plan.xs_unit_off.as<int64_t>(), n_units,
+                       plan.xs_ent.as<uint32_t>(), plan.xs_unit_off.as<int64_t>(), n_units, row_bits,
                        out.as<unsigned long long>());
     unsigned long long h[3];
     CGA_HIP(hipMemcpyAsync(h, out.p, 24, hipMemcpyDeviceToHost, stream));
@@ -1164,6 +1171,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_n_tiles   = n_tiles;
   plan.xs_n_win     = n_win;
   plan.xs_slice_shift = slice_shift;
+  plan.xs_row_bits  = row_bits;
 }
 
 PullPlan& get_plan(Handle const& h, Graph& g)
@@ -1493,16 +1501,14 @@ void session_setup(Session& s, PagerankArgs const& a)
     bk.n_blocks   = static_cast<int>(std::min<int64_t>(need, block_cap[b]));
     bk.block_begin = begin;
     begin += bk.n_blocks;
-    if (b == 0) {  // XS workgroups come right after the hub items
-      s.xs_block_begin = begin;
-      s.n_xs_blocks    = s.xs_on ? static_cast<int>(std::min<int64_t>(
-                                      static_cast<int64_t>(plan.xs_n_tiles) * kXsSlices,
-                                      std::getenv("CUGRAPH_AMD_XS_BLOCKS")
-                                        ? std::atoi(std::getenv("CUGRAPH_AMD_XS_BLOCKS"))
-                                        : 1024))
-                                 : 0;
-      begin += s.n_xs_blocks;
-    }
+  }
+  // XS tiles run in their own launch (xs_kernel): 4096 threads per CU whatever the workgroup size
+  s.xs_block_begin = 0;
+  s.n_xs_blocks    = 0;
+  if (s.xs_on) {
+    char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
+    int want       = xb ? std::atoi(xb) : 1024;  // 4 workgroups (LDS-bound) on each of 256 CUs
+    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_tiles) * kXsSlices, want));
   }
   if (s.xs_on) {
     s.xs_partial.alloc(static_cast<size_t>(kXsSlices * plan.xs_n_rows) * vb);
@@ -1572,16 +1578,13 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   {
     char const* am      = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
     a.xs.affinity_mode = am ? std::atoi(am) : 0;
-    char const* dd      = std::getenv("CUGRAPH_AMD_XS_DEDUPE");
-    a.xs.dedupe         = dd ? std::atoi(dd) : 1;
-    char const* fh      = std::getenv("CUGRAPH_AMD_XS_FAKE_HOT");
-    a.xs.fake_hot       = fh ? static_cast<uint32_t>(std::atoll(fh)) : 0u;
   }
   if (s.xs_on) {
     PullPlan const& plan = *s.graph->plan;
     a.xs.ent       = plan.xs_ent.as<uint32_t>();
     a.xs.n_win     = plan.xs_n_win;
     a.xs.slice_shift = plan.xs_slice_shift;
+    a.xs.row_bits  = plan.xs_row_bits;
     a.xs.w         = plan.xs_w.p ? plan.xs_w.as<ValT>() : nullptr;
     a.xs.unit_off  = plan.xs_unit_off.as<int64_t>();
     a.xs.tile_row  = plan.xs_tile_row.as<int32_t>();
@@ -1595,13 +1598,33 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   for (int b = 0; b < kNumBuckets; ++b) a.buckets[b] = s.buckets[b];
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
+  if (s.xs_on && s.n_xs_blocks > 0) {
+    auto launch_xs = [&](auto weighted_tag, auto threads_tag, auto bits_tag) {
+      constexpr bool W  = decltype(weighted_tag)::value;
+      constexpr int T   = decltype(threads_tag)::value;
+      constexpr int RB  = decltype(bits_tag)::value;
+      constexpr size_t lds = sizeof(double) << RB;
+      auto kern = xs_kernel<OffT, ValT, W, T, RB>;
+      if (lds > 48 * 1024)
+        CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(T), lds, stream, a);
+    };
+    auto by_bits = [&](auto weighted_tag) {
+      launch_xs(weighted_tag, std::integral_constant<int, kThreads>{}, std::integral_constant<int, kXsRowBits>{});
+    };
+    if (g.weights) by_bits(std::true_type{});
+    else by_bits(std::false_type{});
+  }
+  // the dominant kernel: xs_kernel when the graph has XS tiles, else spmv_kernel
+  if (ev_kernel_end && s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
   if (g.weights)
     hipLaunchKernelGGL((spmv_kernel<OffT, ValT, true>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
                        stream, a);
   else
     hipLaunchKernelGGL((spmv_kernel<OffT, ValT, false>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
                        stream, a);
-  if (ev_kernel_end) CGA_HIP(hipEventRecord(ev_kernel_end, stream));  // spmv_kernel alone
+  if (ev_kernel_end && !s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
   if (s.n_hub_blocks > 0)
     hipLaunchKernelGGL((hub_finish_kernel<OffT, ValT>), dim3(s.n_hub_blocks), dim3(kThreads), 0,
                        stream, a, s.hub_row_item_off, s.partials.as<double>() + 2 * s.n_spmv_blocks);
@@ -1780,10 +1803,16 @@ void session_info(Session& s, int64_t info[8])
   info[4]      = s.buckets[0].count;
   info[5]      = s.n_hub_items;
   info[6]      = s.n_spmv_blocks;
-  // algorithmic bytes of spmv_kernel alone: the rank update of the XS / hub rows (5 values per
-  // row) is done by xs_finish_kernel / hub_finish_kernel
-  int64_t finished_elsewhere = (s.xs_on ? s.graph->plan->xs_n_rows : 0) + s.buckets[0].count;
-  info[7]      = info[0] - 5 * finished_elsewhere * bval;
+  // algorithmic bytes of the dominant kernel alone.  xs_kernel: the index (+weight) stream and
+  // the offsets of the XS rows, and the one read of the gathered vector; the other four V-terms
+  // of those rows belong to xs_finish_kernel.  Without XS tiles: spmv_kernel does everything
+  // except the rank update of the hub rows (hub_finish_kernel).
+  if (s.xs_on) {
+    PullPlan const& plan = *s.graph->plan;
+    info[7] = plan.xs_n_edges * (4 + bw) + plan.xs_n_rows * boff + s.x_len * bval;
+  } else {
+    info[7] = info[0] - 4 * s.buckets[0].count * bval;
+  }
 }
 
 void session_exchange_buffers(Session& s, void** x_full, void** scalars)

@@ -71,7 +71,7 @@ class PagerankSession:
         code = self._lib.cugraph_amd_pagerank_session_info(self._ptr, arr, ctypes.byref(err))
         _capi.check(code, err, "cugraph_amd_pagerank_session_info")
         keys = ["bytes_per_iteration", "edges", "low_degree_vertices", "mid_degree_vertices",
-                "hub_vertices", "hub_work_items", "spmv_workgroups", "spmv_kernel_bytes"]
+                "hub_vertices", "hub_work_items", "spmv_workgroups", "dominant_kernel_bytes"]
         return dict(zip(keys, [int(x) for x in arr]))
 
     def exchange_buffers(self):

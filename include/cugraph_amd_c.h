@@ -346,8 +346,9 @@ cugraph_error_code_t cugraph_amd_pagerank_session_iterate(cugraph_amd_pagerank_s
                                                           size_t n, cugraph_error_t** error);
 
 /* As iterate(), but brackets every iteration and its SpMV launch with HIP events on the handle's
- * stream, synchronises, and returns the n per-iteration and per-SpMV-kernel durations in
- * milliseconds (either output may be NULL).  For bench.py's roofline figure. */
+ * stream, synchronises, and returns the n per-iteration durations and the durations of the
+ * dominant kernel (xs_kernel, or spmv_kernel for graphs without XS tiles) in milliseconds
+ * (either output may be NULL).  For bench.py's roofline figure. */
 cugraph_error_code_t cugraph_amd_pagerank_session_timed_iterate(
   cugraph_amd_pagerank_session_t* session, size_t n, float* iteration_ms, float* spmv_kernel_ms,
   cugraph_error_t** error);
@@ -380,8 +381,8 @@ cugraph_error_code_t cugraph_amd_pagerank_session_result(cugraph_amd_pagerank_se
 
 /* info[0]=algorithmic bytes per iteration, [1]=edges per iteration,
  * [2]=low-degree vertices, [3]=mid-degree vertices, [4]=hub vertices, [5]=hub work items,
- * [6]=workgroups of the SpMV launch, [7]=algorithmic bytes of the spmv_kernel launch alone (the
- * rank update of rows whose sums are finished by xs_finish_kernel / hub_finish_kernel excluded) */
+ * [6]=workgroups of the spmv_kernel launch, [7]=algorithmic bytes of the dominant kernel alone
+ * (xs_kernel when the graph runs on XS tiles, else spmv_kernel) */
 cugraph_error_code_t cugraph_amd_pagerank_session_info(cugraph_amd_pagerank_session_t* session,
                                                        int64_t info[8], cugraph_error_t** error);
 
