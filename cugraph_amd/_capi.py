@@ -75,6 +75,15 @@ SIGNATURES = {
     "cugraph_centrality_result_get_num_iterations": (_sz, [_vp]),
     "cugraph_centrality_result_converged": (_int, [_vp]),
     "cugraph_centrality_result_free": (None, [_vp]),
+    "cugraph_eigenvector_centrality": (_int, [_vp, _vp, _dbl, _sz, _int, _vpp, _vpp]),
+    "cugraph_katz_centrality": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _sz, _int, _vpp, _vpp]),
+    "cugraph_hits": (_int, [_vp, _vp, _dbl, _sz, _vp, _vp, _int, _int, _vpp, _vpp]),
+    "cugraph_hits_result_get_vertices": (_vp, [_vp]),
+    "cugraph_hits_result_get_hubs": (_vp, [_vp]),
+    "cugraph_hits_result_get_authorities": (_vp, [_vp]),
+    "cugraph_hits_result_get_hub_score_differences": (_dbl, [_vp]),
+    "cugraph_hits_result_get_number_of_iterations": (_sz, [_vp]),
+    "cugraph_hits_result_free": (None, [_vp]),
     "cugraph_pagerank": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _sz, _int, _vpp, _vpp]),
     "cugraph_pagerank_allow_nonconvergence": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _sz,
                                                      _int, _vpp, _vpp]),
@@ -122,6 +131,12 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C cugraph_amd/csrc` (there is no CPU fallback)")
+        # PyTorch ships its own HIP runtime and is this package's device-memory plumbing: import
+        # it first, so that the library binds to the runtime torch has already loaded.  (Loaded
+        # the other way round, the process ends up with /opt/rocm's runtime initialised and
+        # torch's own initialisation then finds "No HIP GPUs".)
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

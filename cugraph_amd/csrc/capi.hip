@@ -790,6 +790,82 @@ size_t cugraph_centrality_result_get_num_iterations(cugraph_centrality_result_t*
 bool_t cugraph_centrality_result_converged(cugraph_centrality_result_t* result) { return as<CentralityResult>(result)->converged ? TRUE : FALSE; }
 void cugraph_centrality_result_free(cugraph_centrality_result_t* result) { delete as<CentralityResult>(result); }
 
+// ------------------------------------------------------------------ Katz / eigenvector / HITS
+cugraph_error_code_t cugraph_katz_centrality(const cugraph_resource_handle_t* handle,
+                                             cugraph_graph_t* graph,
+                                             const cugraph_type_erased_device_array_view_t* betas,
+                                             double alpha, double beta, double epsilon,
+                                             size_t max_iterations, bool_t do_expensive_check,
+                                             cugraph_centrality_result_t** result,
+                                             cugraph_error_t** error)
+{
+  if (error) *error = nullptr;
+  if (result) *result = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph || !result) return fail(error, CUGRAPH_INVALID_INPUT, "graph / result pointer is NULL");
+  return guarded(error, [&] {
+    *result = reinterpret_cast<cugraph_centrality_result_t*>(
+      run_katz(*as<Handle>(handle), *as<Graph>(graph), as<ArrayView>(betas), alpha, beta, epsilon,
+               max_iterations, do_expensive_check != FALSE));
+  });
+}
+
+cugraph_error_code_t cugraph_eigenvector_centrality(const cugraph_resource_handle_t* handle,
+                                                    cugraph_graph_t* graph, double epsilon,
+                                                    size_t max_iterations, bool_t do_expensive_check,
+                                                    cugraph_centrality_result_t** result,
+                                                    cugraph_error_t** error)
+{
+  if (error) *error = nullptr;
+  if (result) *result = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph || !result) return fail(error, CUGRAPH_INVALID_INPUT, "graph / result pointer is NULL");
+  return guarded(error, [&] {
+    *result = reinterpret_cast<cugraph_centrality_result_t*>(run_eigenvector(
+      *as<Handle>(handle), *as<Graph>(graph), epsilon, max_iterations, do_expensive_check != FALSE));
+  });
+}
+
+cugraph_error_code_t cugraph_hits(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, double epsilon,
+  size_t max_iterations, const cugraph_type_erased_device_array_view_t* initial_hubs_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_hubs_guess_values, bool_t normalize,
+  bool_t do_expensive_check, cugraph_hits_result_t** result, cugraph_error_t** error)
+{
+  if (error) *error = nullptr;
+  if (result) *result = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph || !result) return fail(error, CUGRAPH_INVALID_INPUT, "graph / result pointer is NULL");
+  return guarded(error, [&] {
+    *result = reinterpret_cast<cugraph_hits_result_t*>(
+      run_hits(*as<Handle>(handle), *as<Graph>(graph), epsilon, max_iterations,
+               as<ArrayView>(initial_hubs_guess_vertices), as<ArrayView>(initial_hubs_guess_values),
+               normalize != FALSE, do_expensive_check != FALSE));
+  });
+}
+
+cugraph_type_erased_device_array_view_t* cugraph_hits_result_get_vertices(cugraph_hits_result_t* result)
+{
+  auto* r = as<HitsResult>(result);
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+    new_view(r->vertex_ids->data, r->vertex_ids->size, r->vertex_ids->type));
+}
+cugraph_type_erased_device_array_view_t* cugraph_hits_result_get_hubs(cugraph_hits_result_t* result)
+{
+  auto* r = as<HitsResult>(result);
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+    new_view(r->hubs->data, r->hubs->size, r->hubs->type));
+}
+cugraph_type_erased_device_array_view_t* cugraph_hits_result_get_authorities(cugraph_hits_result_t* result)
+{
+  auto* r = as<HitsResult>(result);
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+    new_view(r->authorities->data, r->authorities->size, r->authorities->type));
+}
+double cugraph_hits_result_get_hub_score_differences(cugraph_hits_result_t* result) { return as<HitsResult>(result)->hub_score_differences; }
+size_t cugraph_hits_result_get_number_of_iterations(cugraph_hits_result_t* result) { return as<HitsResult>(result)->number_of_iterations; }
+void cugraph_hits_result_free(cugraph_hits_result_t* result) { delete as<HitsResult>(result); }
+
 // ------------------------------------------------------------------ PageRank
 cugraph_error_code_t cugraph_pagerank(
   const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,

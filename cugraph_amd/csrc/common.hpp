@@ -191,6 +191,21 @@ struct CentralityResult {
   }
 };
 
+// reference: cpp/src/c_api/hits.cpp (cugraph_hits_result_t)
+struct HitsResult {
+  Array* vertex_ids{nullptr};
+  Array* hubs{nullptr};
+  Array* authorities{nullptr};
+  double hub_score_differences{0.0};
+  size_t number_of_iterations{0};
+  ~HitsResult()
+  {
+    delete vertex_ids;
+    delete hubs;
+    delete authorities;
+  }
+};
+
 // ---------------------------------------------------------------- graph_build.hip
 struct CompressedOut {
   DevBuf offsets;  // int32 or int64
@@ -263,6 +278,15 @@ struct PagerankArgs {
 
 CentralityResult* run_pagerank(Handle const& h, Graph& g, PagerankArgs const& a);
 void destroy_plan(PullPlan* p);
+
+// ---------------------------------------------------------------- centrality.hip
+CentralityResult* run_katz(Handle const& h, Graph& g, ArrayView const* betas, double alpha, double beta,
+                           double epsilon, size_t max_iterations, bool do_expensive_check);
+CentralityResult* run_eigenvector(Handle const& h, Graph& g, double epsilon, size_t max_iterations,
+                                  bool do_expensive_check);
+HitsResult* run_hits(Handle const& h, Graph& g, double epsilon, size_t max_iterations,
+                     ArrayView const* guess_v, ArrayView const* guess_x, bool normalize,
+                     bool do_expensive_check);
 
 // ---------------------------------------------------------------- rmat.hip
 void rmat_generate(hipStream_t stream, int scale, uint64_t first, uint64_t count, uint64_t seed,

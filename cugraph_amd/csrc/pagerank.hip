@@ -127,6 +127,7 @@ struct IterArgs {
   int personalized;
   uint32_t gather_mask;  // 0xFFFFFFFF; a timing aid can narrow it (CUGRAPH_AMD_GATHER_MASK)
   int64_t vertex_first;
+  ValT* raw_out;         // not nullptr: plain SpMV, row sums go here and nothing else happens
   int32_t const* x_pos;  // slot of row v in the gathered vector, -1: nobody gathers it; nullptr: vertex_first + v
   HubItem const* hub_items;  // bucket 0 works on these instead of whole rows
   int64_t n_hub_items;
@@ -172,6 +173,10 @@ struct Epilogue {
   }
   __device__ inline void finish(int64_t v, ValT weighted_sum)
   {
+    if (a.raw_out) {
+      a.raw_out[v] = weighted_sum;
+      return;
+    }
     ValT pr = base + a.alpha * weighted_sum;
     if (a.pers_dense) pr += teleport * a.pers_dense[v];
     ValT old = __builtin_nontemporal_load(a.pr_old + v);
@@ -344,6 +349,7 @@ __device__ inline void isolated_bucket(IterArgs<OffT, ValT> const& a, Bucket con
   int64_t t = (int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x;
   int64_t n = (int64_t)b.n_blocks * kThreads;
   bool vec  = b.list == nullptr && a.pers_dense == nullptr && a.x_pos == nullptr &&
+             a.raw_out == nullptr &&
              (a.vertex_first & 3) == 0;
   if (!vec) {
     for (int64_t i = t; i < b.count; i += n)
@@ -1326,6 +1332,63 @@ void dense_from_pairs(hipStream_t stream, ArrayView const* ids, ArrayView const*
               std::string(what) + ": vertex ids outside this graph's vertex range");
 }
 
+// launch geometry of a session: bucket block ranges, XS queues and partials, hub work items
+template <typename ValT>
+int session_geometry(Session& s, PullPlan& plan)
+{
+  size_t vb  = sizeof(ValT);
+  int64_t nl = s.n_local;
+  // ---- launch geometry: all buckets in one grid, hubs first
+  int begin = 0;
+  // timing aid: CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets (results are then wrong)
+  char const* mask_env = std::getenv("CUGRAPH_AMD_BUCKET_MASK");
+  int bucket_mask      = mask_env ? std::atoi(mask_env) : 0x1F;
+  int const group_width[kNumBuckets] = {kThreads, 64, 16, 1, 1};
+  int const block_cap[kNumBuckets]   = {4096, 3072, 3072, 2048, 2048};
+  s.xs_on = plan.xs_on && ((bucket_mask >> 5) & 1 || !mask_env);
+  for (int b = 0; b < kNumBuckets; ++b) {
+    Bucket& bk    = s.buckets[b];
+    bk.count      = ((bucket_mask >> b) & 1) ? plan.counts[b] : 0;
+    if (plan.xs_on && b <= 2) bk.count = 0;  // rows with >= kXsMinDegree edges: XS tiles
+    bk.list       = plan.lists[b].p ? plan.lists[b].as<int32_t>() : nullptr;
+    bk.first      = plan.firsts[b];
+    int64_t need  = (bk.count * group_width[b] + kThreads - 1) / kThreads;
+    if (b == 0) need = bk.count > 0 ? plan.n_hub_items : 0;  // one workgroup per hub work item
+    bk.n_blocks   = static_cast<int>(std::min<int64_t>(need, block_cap[b]));
+    bk.block_begin = begin;
+    begin += bk.n_blocks;
+  }
+  // XS tiles run in their own launch (xs_kernel): 4096 threads per CU whatever the workgroup size
+  s.xs_block_begin = 0;
+  s.n_xs_blocks    = 0;
+  if (s.xs_on) {
+    char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
+    int want       = xb ? std::atoi(xb) : 1024;  // 4 workgroups (LDS-bound) on each of 256 CUs
+    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_tiles) * kXsSlices, want));
+  }
+  if (s.xs_on) {
+    s.xs_partial.alloc(static_cast<size_t>(kXsSlices * plan.xs_n_rows) * vb);
+    s.xs_counters.alloc(256);
+    s.n_xs_finish_blocks = grid_for(plan.xs_n_rows, 1024);
+  }
+  s.n_spmv_blocks = std::max(begin, 1);
+  s.n_hub_items   = s.buckets[0].count > 0 ? plan.n_hub_items : 0;
+  s.n_hub_blocks  = s.n_hub_items > 0 ? grid_for(s.buckets[0].count, 256) : 0;
+  s.hub_items     = plan.hub_items.p ? plan.hub_items.as<HubItem>() : nullptr;
+  s.hub_row_item_off = plan.hub_row_item_off.p ? plan.hub_row_item_off.as<int64_t>() : nullptr;
+  s.hub_item_partial.alloc(static_cast<size_t>(s.n_hub_items > 0 ? s.n_hub_items : 1) * sizeof(double));
+  s.n_pers_blocks = (s.personalized && !s.pers_is_dense && s.n_pers > 0)
+                      ? grid_for(s.n_pers, 256)
+                      : 0;
+  int n_prep_blocks = grid_for(nl, 1024);
+  int n_partials    = std::max(s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks + s.n_pers_blocks,
+                               n_prep_blocks);
+  CGA_EXPECTS(n_partials <= kMaxPartials, CUGRAPH_UNKNOWN_ERROR, "internal: too many partials");
+  s.partials.alloc(static_cast<size_t>(2 * n_partials) * sizeof(double));
+
+  return n_prep_blocks;
+}
+
 template <typename ValT>
 void session_setup(Session& s, PagerankArgs const& a)
 {
@@ -1482,53 +1545,7 @@ void session_setup(Session& s, PagerankArgs const& a)
     }
   }
 
-  // ---- launch geometry: all buckets in one grid, hubs first
-  int begin = 0;
-  // timing aid: CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets (results are then wrong)
-  char const* mask_env = std::getenv("CUGRAPH_AMD_BUCKET_MASK");
-  int bucket_mask      = mask_env ? std::atoi(mask_env) : 0x1F;
-  int const group_width[kNumBuckets] = {kThreads, 64, 16, 1, 1};
-  int const block_cap[kNumBuckets]   = {4096, 3072, 3072, 2048, 2048};
-  s.xs_on = plan.xs_on && ((bucket_mask >> 5) & 1 || !mask_env);
-  for (int b = 0; b < kNumBuckets; ++b) {
-    Bucket& bk    = s.buckets[b];
-    bk.count      = ((bucket_mask >> b) & 1) ? plan.counts[b] : 0;
-    if (plan.xs_on && b <= 2) bk.count = 0;  // rows with >= kXsMinDegree edges: XS tiles
-    bk.list       = plan.lists[b].p ? plan.lists[b].as<int32_t>() : nullptr;
-    bk.first      = plan.firsts[b];
-    int64_t need  = (bk.count * group_width[b] + kThreads - 1) / kThreads;
-    if (b == 0) need = bk.count > 0 ? plan.n_hub_items : 0;  // one workgroup per hub work item
-    bk.n_blocks   = static_cast<int>(std::min<int64_t>(need, block_cap[b]));
-    bk.block_begin = begin;
-    begin += bk.n_blocks;
-  }
-  // XS tiles run in their own launch (xs_kernel): 4096 threads per CU whatever the workgroup size
-  s.xs_block_begin = 0;
-  s.n_xs_blocks    = 0;
-  if (s.xs_on) {
-    char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
-    int want       = xb ? std::atoi(xb) : 1024;  // 4 workgroups (LDS-bound) on each of 256 CUs
-    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_tiles) * kXsSlices, want));
-  }
-  if (s.xs_on) {
-    s.xs_partial.alloc(static_cast<size_t>(kXsSlices * plan.xs_n_rows) * vb);
-    s.xs_counters.alloc(256);
-    s.n_xs_finish_blocks = grid_for(plan.xs_n_rows, 1024);
-  }
-  s.n_spmv_blocks = std::max(begin, 1);
-  s.n_hub_items   = s.buckets[0].count > 0 ? plan.n_hub_items : 0;
-  s.n_hub_blocks  = s.n_hub_items > 0 ? grid_for(s.buckets[0].count, 256) : 0;
-  s.hub_items     = plan.hub_items.p ? plan.hub_items.as<HubItem>() : nullptr;
-  s.hub_row_item_off = plan.hub_row_item_off.p ? plan.hub_row_item_off.as<int64_t>() : nullptr;
-  s.hub_item_partial.alloc(static_cast<size_t>(s.n_hub_items > 0 ? s.n_hub_items : 1) * sizeof(double));
-  s.n_pers_blocks = (s.personalized && !s.pers_is_dense && s.n_pers > 0)
-                      ? grid_for(s.n_pers, 256)
-                      : 0;
-  int n_prep_blocks = grid_for(nl, 1024);
-  int n_partials    = std::max(s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks + s.n_pers_blocks,
-                               n_prep_blocks);
-  CGA_EXPECTS(n_partials <= kMaxPartials, CUGRAPH_UNKNOWN_ERROR, "internal: too many partials");
-  s.partials.alloc(static_cast<size_t>(2 * n_partials) * sizeof(double));
+  int n_prep_blocks = session_geometry<ValT>(s, plan);
 
   // ---- x0 and the dangling mass of pr0
   hipLaunchKernelGGL((prep_kernel<ValT>), dim3(n_prep_blocks), dim3(kThreads), 0, stream,
@@ -1541,7 +1558,8 @@ void session_setup(Session& s, PagerankArgs const& a)
 }
 
 template <typename OffT, typename ValT>
-void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end)
+void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end,
+                       ValT const* raw_x = nullptr, ValT* raw_y = nullptr)
 {
   Graph const& g     = *s.cg;
   hipStream_t stream = s.handle->stream;
@@ -1570,6 +1588,10 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   }
   a.vertex_first    = g.vertex_first;
   a.x_pos           = g.x_pos;
+  if (raw_y) {  // plain SpMV for the sibling power iterations (centrality.hip)
+    a.x_cur   = raw_x;
+    a.raw_out = raw_y;
+  }
   a.hub_items        = s.hub_items;
   a.n_hub_items      = s.n_hub_items;
   a.hub_item_partial = s.hub_item_partial.as<double>();
@@ -1631,6 +1653,10 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   if (s.n_xs_finish_blocks > 0)
     hipLaunchKernelGGL((xs_finish_kernel<OffT, ValT>), dim3(s.n_xs_finish_blocks), dim3(kThreads), 0,
                        stream, a, s.partials.as<double>() + 2 * (s.n_spmv_blocks + s.n_hub_blocks));
+  if (raw_y) {
+    CGA_HIP(hipGetLastError());
+    return;
+  }
   if (s.n_pers_blocks > 0)
     hipLaunchKernelGGL((pers_fix_kernel<ValT>), dim3(s.n_pers_blocks), dim3(kThreads), 0, stream,
                        s.pers_v.as<int32_t>(), s.pers_p.as<ValT>(), s.n_pers, a.pr_old, a.pr_new,
@@ -1822,6 +1848,49 @@ void session_exchange_buffers(Session& s, void** x_full, void** scalars)
 }
 
 void session_destroy(Session* s) { delete s; }
+
+// ---- plain SpMV on the same plan and kernels: y[v] = sum over in-edges (u -> v) of x[u] * w
+// x and y are in the order of the graph the kernels run on (see spmv_session_order)
+Session* spmv_session_create(Handle const& h, Graph& g)
+{
+  CGA_EXPECTS(g.store_transposed, CUGRAPH_INVALID_INPUT, "graph must be stored transposed");
+  CGA_EXPECTS(g.num_global_vertices == g.num_vertices && g.x_pos == nullptr, CUGRAPH_NOT_IMPLEMENTED,
+              "partitioned graphs are only supported by PageRank");
+  auto s = std::make_unique<Session>();
+  s->handle   = &h;
+  s->graph    = &g;
+  s->f64      = g.weight_type == FLOAT64;
+  s->n_local  = g.num_vertices;
+  s->n_global = g.num_global_vertices;
+  s->x_len    = g.num_global_vertices;
+  PullPlan& plan = get_plan(h, g);
+  s->cg          = plan.internal ? plan.internal : &g;
+  s->order       = plan.internal ? static_cast<int32_t const*>(plan.internal->number_map) : nullptr;
+  if (s->f64) session_geometry<double>(*s, plan);
+  else session_geometry<float>(*s, plan);
+  s->scal.alloc(2 * sizeof(double));
+  s->ctrl.alloc(sizeof(Ctrl));
+  double never[2] = {0.0, 1e300};  // "previous delta" that never passes the stop check
+  CGA_HIP(hipMemsetAsync(s->ctrl.p, 0, sizeof(Ctrl), h.stream));
+  CGA_HIP(hipMemcpyAsync(s->scal.p, never, sizeof(never), hipMemcpyHostToDevice, h.stream));
+  CGA_HIP(hipStreamSynchronize(h.stream));
+  return s.release();
+}
+
+int32_t const* spmv_session_order(Session& s) { return s.order; }
+
+void spmv_apply(Session& s, void const* x, void* y)
+{
+  if (s.n_local == 0) return;
+  bool o64 = s.cg->off64;
+  if (s.f64) {
+    if (o64) enqueue_iteration<int64_t, double>(s, nullptr, nullptr, static_cast<double const*>(x), static_cast<double*>(y));
+    else enqueue_iteration<int32_t, double>(s, nullptr, nullptr, static_cast<double const*>(x), static_cast<double*>(y));
+  } else {
+    if (o64) enqueue_iteration<int64_t, float>(s, nullptr, nullptr, static_cast<float const*>(x), static_cast<float*>(y));
+    else enqueue_iteration<int32_t, float>(s, nullptr, nullptr, static_cast<float const*>(x), static_cast<float*>(y));
+  }
+}
 bool session_is_f64(Session& s) { return s.f64; }
 int64_t session_num_global(Session& s) { return s.x_len; }
 

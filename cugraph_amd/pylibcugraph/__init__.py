@@ -13,6 +13,7 @@ from .graph_properties import GraphProperties  # noqa: F401
 from .graphs import SGGraph, MGGraph  # noqa: F401
 from .pagerank import pagerank  # noqa: F401
 from .personalized_pagerank import personalized_pagerank  # noqa: F401
+from .centrality import eigenvector_centrality, hits, katz_centrality  # noqa: F401
 
 __all__ = [
     "FailedToConvergeError",
@@ -22,4 +23,7 @@ __all__ = [
     "MGGraph",
     "pagerank",
     "personalized_pagerank",
+    "katz_centrality",
+    "eigenvector_centrality",
+    "hits",
 ]

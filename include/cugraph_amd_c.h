@@ -230,6 +230,46 @@ cugraph_error_code_t cugraph_personalized_pagerank_allow_nonconvergence(
   double epsilon, size_t max_iterations, bool_t do_expensive_check,
   cugraph_centrality_result_t** result, cugraph_error_t** error);
 
+/* ---- sibling power iterations on the same pull SpMV ---- */
+
+/* centrality_algorithms.h:327 (impl cpp/src/c_api/eigenvector_centrality.cpp:55-120,
+ * cpp/src/centrality/eigenvector_centrality_impl.cuh:46-165): x' = normalise_L2(x + A^T x), stop when
+ * sum|x' - x| < V * epsilon; failure to converge is CUGRAPH_UNKNOWN_ERROR without a result. */
+cugraph_error_code_t cugraph_eigenvector_centrality(const cugraph_resource_handle_t* handle,
+                                                    cugraph_graph_t* graph, double epsilon,
+                                                    size_t max_iterations, bool_t do_expensive_check,
+                                                    cugraph_centrality_result_t** result,
+                                                    cugraph_error_t** error);
+
+/* centrality_algorithms.h:360 (impl cpp/src/c_api/katz.cpp:60-150,
+ * cpp/src/centrality/katz_centrality_impl.cuh:43-196): x' = alpha * A^T x + beta (betas[i] for the
+ * vertex with external id i when given), from x = 0, stop when sum|x' - x| < epsilon; the result is
+ * divided by its L2 norm (the C API always normalises). */
+cugraph_error_code_t cugraph_katz_centrality(const cugraph_resource_handle_t* handle,
+                                             cugraph_graph_t* graph,
+                                             const cugraph_type_erased_device_array_view_t* betas,
+                                             double alpha, double beta, double epsilon,
+                                             size_t max_iterations, bool_t do_expensive_check,
+                                             cugraph_centrality_result_t** result,
+                                             cugraph_error_t** error);
+
+/* centrality_algorithms.h:499-597 (impl cpp/src/c_api/hits.cpp, cpp/src/link_analysis/hits_impl.cuh:57-206):
+ * authorities = in-sums of hubs, hubs = out-sums of authorities, both divided by their maximum,
+ * stop when sum|hubs' - hubs| < V * epsilon; `normalize` divides both by their sums at the end.
+ * Edge weights are ignored, as in the reference. */
+typedef struct { int32_t align_; } cugraph_hits_result_t;
+cugraph_type_erased_device_array_view_t* cugraph_hits_result_get_vertices(cugraph_hits_result_t* result);
+cugraph_type_erased_device_array_view_t* cugraph_hits_result_get_hubs(cugraph_hits_result_t* result);
+cugraph_type_erased_device_array_view_t* cugraph_hits_result_get_authorities(cugraph_hits_result_t* result);
+double cugraph_hits_result_get_hub_score_differences(cugraph_hits_result_t* result);
+size_t cugraph_hits_result_get_number_of_iterations(cugraph_hits_result_t* result);
+void cugraph_hits_result_free(cugraph_hits_result_t* result);
+cugraph_error_code_t cugraph_hits(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, double epsilon,
+  size_t max_iterations, const cugraph_type_erased_device_array_view_t* initial_hubs_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_hubs_guess_values, bool_t normalize,
+  bool_t do_expensive_check, cugraph_hits_result_t** result, cugraph_error_t** error);
+
 /* ===================================================================== */
 /* Part 2 -- extensions (no counterpart in the reference)                 */
 /* ===================================================================== */

@@ -1,5 +1,7 @@
 """CPU: pins the oracle (C restatement + NetworkX/SciPy) to every golden vector the reference's
 own tests hold for the PageRank path, and the oracle's parts to each other."""
+import os
+
 import numpy as np
 import pytest
 
@@ -123,3 +125,58 @@ def test_rmat_generator_properties():
     w = oracle.rmat_weights(10000)
     assert w.min() > 0 and w.max() <= 1 and abs(w.mean() - 0.5) < 0.02
     assert ids.size == 1024
+
+
+# ---------------------------------------------------------------- sibling power iterations
+def _centrality_cases(kind):
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")) as f:
+        return json.load(f)["c_api_centrality"][kind]
+
+
+def test_centrality_oracle_matches_reference_goldens():
+    """the numpy restatements reproduce every golden of cpp/tests/c_api/{katz,eigenvector_centrality,
+    hits}_test.c to the 0.001 those tests use"""
+    from oracle import np_centrality as npc
+
+    for c in _centrality_cases("katz"):
+        x, _ = npc.katz_centrality(c["num_vertices"], np.array(c["src"]), np.array(c["dst"]),
+                                   np.array(c["wgt"], np.float32), alpha=c["alpha"], beta=c["beta"],
+                                   epsilon=c["epsilon"], max_iterations=c["max_iterations"])
+        assert np.max(np.abs(x - np.array(c["result"]))) < 1e-3, c["name"]
+    for c in _centrality_cases("eigenvector"):
+        x, _ = npc.eigenvector_centrality(c["num_vertices"], np.array(c["src"]), np.array(c["dst"]),
+                                          np.array(c["wgt"], np.float32), epsilon=c["epsilon"],
+                                          max_iterations=c["max_iterations"])
+        assert np.max(np.abs(x - np.array(c["result"]))) < 1e-3, c["name"]
+    for c in _centrality_cases("hits"):
+        init = None
+        if "initial_hubs" in c:
+            init = np.zeros(c["num_vertices"])
+            init[c["initial_vertices"]] = c["initial_hubs"]
+        h, a, _, _ = npc.hits(c["num_vertices"], np.array(c["src"]), np.array(c["dst"]),
+                              epsilon=c["epsilon"], max_iterations=c["max_iterations"],
+                              initial_hubs=init, normalize=c["normalize"])
+        assert np.max(np.abs(h - np.array(c["hubs"]))) < 1e-3, c["name"]
+        assert np.max(np.abs(a - np.array(c["authorities"]))) < 1e-3, c["name"]
+
+
+def test_centrality_oracle_matches_networkx():
+    import networkx as nx
+    from oracle import np_centrality as npc
+
+    src, dst, wgt = load_csv("karate.csv")
+    G = nx.DiGraph()
+    G.add_weighted_edges_from(zip(src.tolist(), dst.tolist(), wgt.tolist()))
+    n = 34
+    want = nx.katz_centrality(G, alpha=0.05, beta=1.0, max_iter=1000, tol=1e-12, weight="weight")
+    x, _ = npc.katz_centrality(n, src, dst, wgt, alpha=0.05, beta=1.0, epsilon=1e-12, max_iterations=1000)
+    assert np.max(np.abs(x - np.array([want[i] for i in range(n)]))) < 1e-9
+    want = nx.eigenvector_centrality(G, max_iter=2000, tol=1e-13, weight="weight")
+    x, _ = npc.eigenvector_centrality(n, src, dst, wgt, epsilon=1e-15, max_iterations=5000)
+    assert np.max(np.abs(x - np.array([want[i] for i in range(n)]))) < 1e-7
+    hw, aw = nx.hits(nx.DiGraph(list(zip(src.tolist(), dst.tolist()))), max_iter=1000, tol=1e-14)
+    h, a, _, _ = npc.hits(n, src, dst, epsilon=1e-15, max_iterations=5000, normalize=True)
+    assert np.max(np.abs(h - np.array([hw[i] for i in range(n)]))) < 1e-8
+    assert np.max(np.abs(a - np.array([aw[i] for i in range(n)]))) < 1e-8
