@@ -370,7 +370,8 @@ HitsResult* hits_impl(Handle const& h, Graph& g, double epsilon_d, size_t max_it
   Ops<T> ops(h.stream, n);
   size_t vb = sizeof(T) * static_cast<size_t>(n > 0 ? n : 1);
   // plain copies of both orientations without weights: hits_impl.cuh ignores edge weights
-  std::unique_ptr<Graph> fwd, rev;
+  std::unique_ptr<Graph> fwd;
+  Graph* rev = nullptr;  // cached on the graph
   SessionHolder sa, sb;
   DevBuf hubs(vb), hubs_new(vb), auth(vb), tmp_in(vb), tmp_out(vb);
   if (n > 0) {
@@ -395,7 +396,8 @@ HitsResult* hits_impl(Handle const& h, Graph& g, double epsilon_d, size_t max_it
                              hipMemcpyDeviceToDevice, h.stream));
       ga = fwd.get();
     }
-    rev.reset(reversed_unweighted(h, g));
+    if (!g.reversed) g.reversed = reversed_unweighted(h, g);
+    rev = g.reversed;
     sa.s = spmv_session_create(h, *ga);
     sb.s = spmv_session_create(h, *rev);
     int32_t const* oa = spmv_session_order(*sa.s);

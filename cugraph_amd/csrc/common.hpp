@@ -174,6 +174,7 @@ struct Graph {
   int64_t ext_range{0};
 
   PullPlan* plan{nullptr};  // cached by the first PageRank call on this graph
+  Graph* reversed{nullptr};  // the other orientation without weights, cached by the first HITS call
 
   int64_t minor_space() const { return num_source_slots > 0 ? num_source_slots : num_global_vertices; }
   ~Graph();

@@ -629,6 +629,8 @@ void transpose_graph(Handle const& h, Graph& g)
     destroy_plan(g.plan);
     g.plan = nullptr;
   }
+  delete g.reversed;
+  g.reversed = nullptr;
 }
 
 Graph::~Graph()
@@ -640,6 +642,7 @@ Graph::~Graph()
   if (ext_lookup) (void)hipFree(ext_lookup);
   if (x_pos) (void)hipFree(x_pos);
   if (plan) destroy_plan(plan);
+  delete reversed;
 }
 
 // as compress_coo, without weights, plus perm[k] = input position of the edge stored at k

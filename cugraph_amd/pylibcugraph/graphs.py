@@ -13,7 +13,10 @@ class _GPUGraph:
     def __del__(self):
         ptr = getattr(self, "c_graph_ptr", None)
         if ptr:
-            _capi.load().cugraph_sg_graph_free(ptr)
+            try:
+                _capi.load().cugraph_sg_graph_free(ptr)
+            except TypeError:  # interpreter shutdown: the module globals are already gone
+                pass
             self.c_graph_ptr = None
 
     def info(self):
