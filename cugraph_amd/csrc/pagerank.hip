@@ -429,16 +429,18 @@ __device__ inline void stream_load4(uint32_t const* p, uint32_t* r)
 // (slice, row); xs_finish_kernel adds the 8 partials and runs the epilogue.  Workgroups pull
 // tiles from the queue of the XCD they run on (HW_REG_XCC_ID) and steal from the other queues
 // when theirs is empty, so the result never depends on where a workgroup was placed.
-template <typename OffT, typename ValT, bool WEIGHTED, int THREADS, int ROWBITS>
+__device__ unsigned long long xs_prof_buf[1024 * 8];
+
+template <typename OffT, typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EXP = 0>
 __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
 {
-  using XsAcc = double;
+  using XsAcc = std::conditional_t<EXP == 2, float, double>;
   constexpr int kLowBits       = 32 - ROWBITS;
   constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
   constexpr int EPL            = kXsEntriesPerLane;
   constexpr uint32_t kPass     = THREADS * EPL;  // entries per pass of the workgroup
   extern __shared__ double xs_lds[];
-  XsAcc* acc = xs_lds;  // [2^ROWBITS]
+  XsAcc* acc = reinterpret_cast<XsAcc*>(xs_lds);  // [2^ROWBITS]
   __shared__ int s_tile;
   if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
   XsArgs<ValT> const& xs = a.xs;
@@ -446,9 +448,11 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
   int const my  = xs.affinity_mode == 0   ? static_cast<int>(xcc_id() & (kXsSlices - 1))
                   : xs.affinity_mode == 1 ? static_cast<int>(blockIdx.x & (kXsSlices - 1))
                                           : static_cast<int>((blockIdx.x >> 3) & (kXsSlices - 1));
+  unsigned long long pt_setup = 0, pt_pass = 0, pt_wb = 0, pt_n = 0, pt_stolen = 0, pt_t0 = wall_clock64(), pt_a = 0, pt_b = 0;
   for (int rot = 0; rot < kXsSlices; ++rot) {
     int const k = (my + rot) & (kXsSlices - 1);
     while (true) {
+      if constexpr (EXP == 5) pt_a = wall_clock64();
       if (tid == 0) s_tile = atomicAdd(&xs.counters[k], 1);
       __syncthreads();
       int const t = s_tile;
@@ -484,40 +488,80 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
         return c;
       };
       uint32_t const low_mask = (1u << shift) - 1u;
-      // one pass of the workgroup over THREADS * EPL entries (EPL per lane).  FAST: all of them exist and
-      // lie in one window (decided on uniform values), so no per-entry predicates or windows.
-      auto pass = [&](auto fast_tag, uint32_t pb, uint32_t win_uniform) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        // entry e of lane tid: pb + e * THREADS + tid, so that the 64 lanes of one gather instruction
-        // hold 64 CONSECUTIVE entries (ascending sources: few cache lines per instruction)
+      // One pass of the workgroup covers THREADS * EPL entries, EPL per lane; entry e of lane tid is
+      // pb + e * THREADS + tid, so that the 64 lanes of one gather instruction hold 64 CONSECUTIVE
+      // entries (ascending sources: few cache lines per instruction).  The loop is software
+      // pipelined: the entries of pass i+1 are requested right after the gathers of pass i were
+      // issued, so their HBM latency hides behind the gathers instead of adding to them (vector
+      // memory returns in order: gathers first, then the prefetch).  FAST: all entries of the pass
+      // exist and lie in one window (decided on uniform values), so no per-entry predicates.
+      uint32_t en[EPL];
+      ValT w[EPL];
+      // loads without predicates (a branch around a load defeats the compiler's vmcnt bookkeeping):
+      // positions past the unit's end are clamped to its last entry and ignored by the pass
+      uint32_t const q_last = (rend > 0 ? rend : 1u) - 1u;
+      auto fetch = [&](uint32_t pb, uint32_t* en_out, ValT* w_out) {
         uint32_t const pos = pb + static_cast<uint32_t>(tid);
-        uint32_t en[EPL];
-        ValT w[EPL];
-        bool p[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           uint32_t q = pos + e * THREADS;
-          p[e]       = FAST || (q >= rbeg && q < rend);
-          en[e]      = p[e] ? __builtin_nontemporal_load(xs.ent + abeg + q) : 0u;
-          if constexpr (WEIGHTED) w[e] = p[e] ? __builtin_nontemporal_load(xs.w + abeg + q) : ValT(0);
+          q          = q < q_last ? q : q_last;
+          en_out[e]  = __builtin_nontemporal_load(xs.ent + abeg + q);
+          if constexpr (WEIGHTED) w_out[e] = __builtin_nontemporal_load(xs.w + abeg + q);
         }
+      };
+      auto pass = [&](auto fast_tag, uint32_t pb, uint32_t win_uniform) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        uint32_t const pos = pb + static_cast<uint32_t>(tid);
+        bool p[EPL];
         uint32_t loc[EPL];  // slice-local source position
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          uint32_t wn = FAST ? win_uniform : window_of(pos + e * THREADS);
+          uint32_t q  = pos + e * THREADS;
+          p[e]        = FAST || (q >= rbeg && q < rend);
+          uint32_t wn = FAST ? win_uniform : window_of(q);
           loc[e]      = (wn << kLowBits) | (en[e] >> ROWBITS);
         }
         ValT xv[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           uint32_t gi = ((loc[e] & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc[e] & low_mask);
-          xv[e]       = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
+          if constexpr (EXP == 3 || EXP == 4)
+            xv[e] = p[e] ? static_cast<ValT>(gi) : ValT(0);
+          else
+            xv[e] = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
         }
+        if constexpr (EXP == 6) {
+          uint32_t const n_ent = rend - rbeg;
+          int const tc = n_ent < 16384u ? 0 : n_ent < 65536u ? 1 : n_ent < 262144u ? 2 : 3;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            uint32_t line = p[e] ? (loc[e] >> 5) : 0xFFFFFFFFu;
+            uint32_t prev = __shfl_up(line, 1);
+            bool first    = p[e] && ((tid & 63) == 0 || prev != line);
+            int sc        = loc[e] < 32768u ? 0 : loc[e] < 524288u ? 1 : 2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              unsigned long long g = __popcll(__ballot(p[e] && sc == c));
+              unsigned long long l = __popcll(__ballot(first && sc == c));
+              if ((tid & 63) == 0 && g) {
+                atomicAdd(&xs_prof_buf[(tc * 3 + c) * 2], g);
+                atomicAdd(&xs_prof_buf[(tc * 3 + c) * 2 + 1], l);
+              }
+            }
+          }
+        }
+        uint32_t en_next[EPL];
+        ValT w_next[EPL];
+        fetch(pb + kPass, en_next, w_next);
         if constexpr (WEIGHTED) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
         }
-        if (few) {
+        if constexpr (EXP == 1 || EXP == 4) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) racc[en[e] & 3] += static_cast<double>(xv[e]);
+        } else if (few) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             double v    = p[e] ? static_cast<double>(xv[e]) : 0.0;
@@ -530,7 +574,14 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
           for (int e = 0; e < EPL; ++e)
             if (p[e]) atomicAdd(&acc[en[e] & kRowMask], static_cast<XsAcc>(xv[e]));
         }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          en[e] = en_next[e];
+          if constexpr (WEIGHTED) w[e] = w_next[e];
+        }
       };
+      if constexpr (EXP == 5) { pt_b = wall_clock64(); pt_setup += pt_b - pt_a; pt_n++; pt_stolen += rot != 0; }
+      fetch(0u, en, w);
       for (uint32_t pb = 0; pb < rend; pb += kPass) {
         uint32_t const w_lo = window_of(pb), w_hi = window_of(pb + kPass - 1);
         if (pb >= rbeg && pb + kPass <= rend && w_lo == w_hi)
@@ -538,11 +589,12 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
         else
           pass(std::false_type{}, pb, 0u);
       }
-      if (few) {
+      if constexpr (EXP == 5) { pt_a = wall_clock64(); pt_pass += pt_a - pt_b; }
+      if (few || EXP == 1 || EXP == 4) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           double v = group_sum(racc[rr], 64);
-          if ((tid & 63) == 0 && rr < rows) atomicAdd(&acc[rr], v);
+          if ((tid & 63) == 0 && rr < rows) atomicAdd(&acc[rr], static_cast<XsAcc>(v));
         }
       }
       __syncthreads();
@@ -550,7 +602,30 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
       for (int i = tid; i < rows; i += THREADS)
         __builtin_nontemporal_store(static_cast<ValT>(acc[i]), out + i);
       __syncthreads();
+      if constexpr (EXP == 5) pt_wb += wall_clock64() - pt_a;
     }
+  }
+  if constexpr (EXP == 5) {
+    if (tid == 0 && blockIdx.x < 1024) {
+      unsigned long long* o = xs_prof_buf + 8 * blockIdx.x;
+      o[0] = my; o[1] = wall_clock64() - pt_t0; o[2] = pt_setup; o[3] = pt_pass; o[4] = pt_wb; o[5] = pt_n; o[6] = pt_stolen;
+      o[7] = pt_t0;
+    }
+  }
+}
+
+void* xs_prof_ptr()
+{
+  void* ptr = nullptr;
+  CGA_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(xs_prof_buf)));
+  return ptr;
+}
+
+__global__ void xs_prof_dump_kernel(int n)
+{
+  for (int i = 0; i < n; ++i) {
+    unsigned long long* o = xs_prof_buf + 8 * i;
+    printf("XSP %d %llu %llu %llu %llu %llu %llu %llu %llu\n", i, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
   }
 }
 
@@ -1099,7 +1174,13 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int64_t min_edges   = min_env ? std::atoll(min_env) : (int64_t(1) << 22);
   if (ne < min_edges || ne == 0 || ne > 0xffffffffLL) return;
   char const* te_env  = std::getenv("CUGRAPH_AMD_XS_TILE_EDGES");
-  int64_t tile_edges  = te_env ? std::atoll(te_env) : kXsTileEdges;
+  // Tile size follows the graph: about 128 full-size tiles (1024 (tile, slice) units, one per
+  // resident workgroup), so that a small graph still fills the chip; capped at kXsTileEdges,
+  // where bigger tiles stop paying.  Measured (ms per iteration, best tile): scale 20 0.15 at
+  // 128 K, scale 22 0.24 at 0.5-1 M, scale 24 0.66 at 2 M, scale 26 2.85 at 8 M.
+  int64_t tile_edges = kXsTileEdges;
+  while (tile_edges > (int64_t(1) << 16) && tile_edges * 128 > ne) tile_edges >>= 1;
+  if (te_env) tile_edges = std::atoll(te_env);
   char const* sh_env  = std::getenv("CUGRAPH_AMD_XS_SLICE_SHIFT");
   int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
   // 13 / 14 (512- / 1024-thread workgroups, 64 / 128 KiB of accumulators, tiles of up to 8192 /
@@ -1621,20 +1702,51 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
   if (s.xs_on && s.n_xs_blocks > 0) {
-    auto launch_xs = [&](auto weighted_tag, auto threads_tag, auto bits_tag) {
+    auto launch_xs = [&](auto weighted_tag, auto threads_tag, auto bits_tag, auto exp_tag) {
       constexpr bool W  = decltype(weighted_tag)::value;
       constexpr int T   = decltype(threads_tag)::value;
       constexpr int RB  = decltype(bits_tag)::value;
       constexpr size_t lds = sizeof(double) << RB;
-      auto kern = xs_kernel<OffT, ValT, W, T, RB>;
+      auto kern = xs_kernel<OffT, ValT, W, T, RB, decltype(exp_tag)::value>;
       if (lds > 48 * 1024)
         CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
       hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(T), lds, stream, a);
     };
+    char const* xt = std::getenv("CUGRAPH_AMD_XS_THREADS");
+    int xs_threads = xt ? std::atoi(xt) : kThreads;
     auto by_bits = [&](auto weighted_tag) {
-      launch_xs(weighted_tag, std::integral_constant<int, kThreads>{}, std::integral_constant<int, kXsRowBits>{});
+      if (xs_threads == 512)
+        launch_xs(weighted_tag, std::integral_constant<int, 512>{}, std::integral_constant<int, kXsRowBits>{},
+                  std::integral_constant<int, 0>{});
+      else
+        launch_xs(weighted_tag, std::integral_constant<int, kThreads>{}, std::integral_constant<int, kXsRowBits>{},
+                  std::integral_constant<int, 0>{});
     };
+    char const* ex = std::getenv("CUGRAPH_AMD_XS_EXP");
+    int exp_mode   = ex ? std::atoi(ex) : 0;
+    if constexpr (std::is_same_v<ValT, float> && std::is_same_v<OffT, int32_t>) {
+      if (!g.weights && exp_mode > 0) {
+        auto go = [&](auto m) {
+          launch_xs(std::false_type{}, std::integral_constant<int, kThreads>{},
+                    std::integral_constant<int, kXsRowBits>{}, m);
+        };
+        if (exp_mode == 1) go(std::integral_constant<int, 1>{});
+        if (exp_mode == 2) go(std::integral_constant<int, 2>{});
+        if (exp_mode == 3) go(std::integral_constant<int, 3>{});
+        if (exp_mode == 4) go(std::integral_constant<int, 4>{});
+        if (exp_mode == 6) {
+          if (s.enqueued == 3) CGA_HIP(hipMemsetAsync(xs_prof_ptr(), 0, 1024 * 64, stream));
+          go(std::integral_constant<int, 6>{});
+          if (s.enqueued == 3) hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, 3);
+        }
+        if (exp_mode == 5) {
+          go(std::integral_constant<int, 5>{});
+          if (s.enqueued == 3) hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, std::min(s.n_xs_blocks, 1024));
+        }
+      } else if (g.weights) by_bits(std::true_type{});
+      else by_bits(std::false_type{});
+    } else
     if (g.weights) by_bits(std::true_type{});
     else by_bits(std::false_type{});
   }
