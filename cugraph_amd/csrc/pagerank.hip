@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 namespace cga {
 
@@ -44,8 +45,9 @@ constexpr int64_t kHubChunk = 32768;  // edges of one hub work item (longer colu
 
 // XS ("XCD-sliced, source-sorted") tiles for the mid-degree rows: see the comment at xs_bucket
 constexpr int kXsSlices       = 8;      // one slice of the source ids per XCD
-constexpr int64_t kXsTileEdges = 1 << 23;  // a tile is a run of rows holding about this many edges,
+constexpr int64_t kXsTileEdges = 1 << 26;  // a tile is a run of rows holding about this many edges,
 constexpr int kXsEntriesPerLane = 8;   // gathers a lane keeps in flight per pass
+constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longer (tile, slice) units are cut
 constexpr int kXsRowBits      = 12;       // a tile never has more than 2^12 rows (32 KiB of fp64 LDS accumulators)
 constexpr int kXsMinDegree    = 4;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
@@ -74,17 +76,23 @@ struct XsArgs {
   uint32_t const* ent;
   ValT const* w;             // [n_edges + 4] or nullptr
   int64_t const* unit_off;   // [n_tiles * 8 * n_win + 1]
+  // one 128-byte record per (slice, work item), see xs_records_kernel: everything a workgroup needs
+  // to start on a piece of a (tile, slice) unit, fetched with one load behind the queue's atomic
+  int64_t const* rec;        // [8][n_items][16]
+  int64_t const* pbase;      // [n_tiles + 1] first partial of each tile (8 * pieces * rows per tile)
+  int n_items;               // work items per slice queue: the pieces of all tiles, biggest tiles first
   int n_win;                 // windows of 2^(32 - row_bits) slice-local positions per slice
   int slice_shift;
   int row_bits;
   int32_t const* tile_row;   // [n_tiles + 1] first row of each tile, relative to row_first
-  ValT* partial;             // [8][n_rows] per-slice partial sums
-  int* counters;             // [8] next tile of each slice's queue
+  ValT* partial;             // per (tile, slice, piece): one partial sum per row of the tile
+  int* counters;             // [8] next item of each slice's queue
   int64_t row_first, n_rows;
   int n_tiles;
-  int block_begin, n_blocks;
   int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
 };
+
+constexpr int kXsRecWords = 16;
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
 struct HubItem {
@@ -140,6 +148,14 @@ __device__ inline uint32_t xcc_id()
 {
   // HW_REG_XCC_ID (20), bits [3:0]: which XCD this wave runs on.  Used for L2 affinity only.
   return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+}
+
+// a value every lane of the wave holds (read from LDS, say) moved to scalar registers
+__device__ inline int64_t uniform64(int64_t v)
+{
+  uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
 template <typename T>
@@ -429,39 +445,65 @@ __device__ inline void stream_load4(uint32_t const* p, uint32_t* r)
 // (slice, row); xs_finish_kernel adds the 8 partials and runs the epilogue.  Workgroups pull
 // tiles from the queue of the XCD they run on (HW_REG_XCC_ID) and steal from the other queues
 // when theirs is empty, so the result never depends on where a workgroup was placed.
+// timing aid (CUGRAPH_AMD_XS_PROFILE=1): per-workgroup time in set-up / passes / write-back
 __device__ unsigned long long xs_prof_buf[1024 * 8];
 
-template <typename OffT, typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EXP = 0>
+template <typename OffT, typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, bool PROFILE = false>
 __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
 {
-  using XsAcc = std::conditional_t<EXP == 2, float, double>;
+  using XsAcc = double;
   constexpr int kLowBits       = 32 - ROWBITS;
   constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
   constexpr int EPL            = kXsEntriesPerLane;
   constexpr uint32_t kPass     = THREADS * EPL;  // entries per pass of the workgroup
   extern __shared__ double xs_lds[];
-  XsAcc* acc = reinterpret_cast<XsAcc*>(xs_lds);  // [2^ROWBITS]
-  __shared__ int s_tile;
+  XsAcc* acc = xs_lds;  // [2^ROWBITS]
+  __shared__ int64_t s_rec[2][kXsRecWords];
   if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
   XsArgs<ValT> const& xs = a.xs;
-  int const tid = threadIdx.x;
+  int const tid  = threadIdx.x;
+  int const lane = tid & 63;
+  bool const wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
   int const my  = xs.affinity_mode == 0   ? static_cast<int>(xcc_id() & (kXsSlices - 1))
                   : xs.affinity_mode == 1 ? static_cast<int>(blockIdx.x & (kXsSlices - 1))
                                           : static_cast<int>((blockIdx.x >> 3) & (kXsSlices - 1));
-  unsigned long long pt_setup = 0, pt_pass = 0, pt_wb = 0, pt_n = 0, pt_stolen = 0, pt_t0 = wall_clock64(), pt_a = 0, pt_b = 0;
+  unsigned long long pt_setup = 0, pt_pass = 0, pt_wb = 0, pt_n = 0, pt_stolen = 0, pt_a = 0, pt_b = 0;
+  unsigned long long const pt_t0 = PROFILE ? wall_clock64() : 0ull;
+  // the accumulators start at zero and every write-back leaves them at zero
+  for (int i = tid; i < (1 << ROWBITS); i += THREADS) acc[i] = 0;
+  // record of queue item q of slice k (lanes 0..15 of the first wave, 8 bytes each); -1: queue empty
+  auto load_record = [&](int k, int q) -> int64_t {
+    int64_t r = -1;
+    if (lane < kXsRecWords && q < xs.n_items)
+      r = xs.rec[(static_cast<int64_t>(k) * xs.n_items + q) * kXsRecWords + lane];
+    return r;
+  };
+  int buf = 0;
   for (int rot = 0; rot < kXsSlices; ++rot) {
     int const k = (my + rot) & (kXsSlices - 1);
+    if constexpr (PROFILE) pt_a = wall_clock64();
+    // the first item of a queue is fetched on the spot, every later one during the item before it
+    if (wave0) {
+      int q = 0;
+      if (lane == 0) q = atomicAdd(&xs.counters[k], 1);
+      q         = __shfl(q, 0);
+      int64_t r = load_record(k, q);
+      if (lane < kXsRecWords) s_rec[buf][lane] = r;
+    }
+    __syncthreads();
     while (true) {
-      if constexpr (EXP == 5) pt_a = wall_clock64();
-      if (tid == 0) s_tile = atomicAdd(&xs.counters[k], 1);
-      __syncthreads();
-      int const t = s_tile;
-      __syncthreads();
-      if (t >= xs.n_tiles) break;
-      int const row0 = xs.tile_row[t];
-      int const rows = xs.tile_row[t + 1] - row0;
-      for (int i = tid; i < rows; i += THREADS) acc[i] = 0;
-      __syncthreads();
+      int64_t const* rec = s_rec[buf];
+      int64_t const head = uniform64(rec[0]);  // tile | piece << 32 | pieces << 40
+      if (head < 0) break;
+      int const t       = static_cast<int>(head & 0xffffffff);
+      uint32_t const piece = static_cast<uint32_t>(head >> 32) & 0xffu;
+      uint32_t const n_pc  = static_cast<uint32_t>(head >> 40) & 0xffu;
+      int const rows    = static_cast<int>(uniform64(rec[1]) >> 32);
+      ValT* const out   = xs.partial + uniform64(rec[2]);
+      // the next item is asked for two passes before this one ends (not earlier: an item reserved
+      // by a busy workgroup is an item an idle one cannot take) and its record one pass later, so
+      // neither round trip is waited for; the record is parked in LDS after the last pass
+      int q_next = 0;
       // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
       // so every lane keeps the 4 row sums in registers and the block reduces them at the end
       bool const few = rows <= 4;
@@ -470,15 +512,17 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
       // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
       // from its position (boundaries relative to the aligned start; up to 8 kept in registers)
       int64_t const u0    = ((int64_t)t * kXsSlices + k) * xs.n_win;
-      int64_t const beg   = xs.unit_off[u0];
-      int64_t const end   = xs.unit_off[u0 + xs.n_win];
+      int64_t const beg   = uniform64(rec[3]);
+      int64_t const end   = uniform64(rec[4]);
       int64_t const abeg  = beg & ~int64_t(3);
       uint32_t const rbeg = static_cast<uint32_t>(beg - abeg);
       uint32_t const rend = static_cast<uint32_t>(end - abeg);
       uint32_t wb[8];
 #pragma unroll
-      for (int w = 1; w < 8; ++w)
-        wb[w] = w < xs.n_win ? static_cast<uint32_t>(xs.unit_off[u0 + w] - abeg) : 0xFFFFFFFFu;
+      for (int w = 1; w < 8; ++w) {
+        int64_t d = uniform64(rec[4 + w]) - abeg;  // INT64_MAX for windows the graph does not have
+        wb[w]     = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : static_cast<uint32_t>(d);
+      }
       auto window_of = [&](uint32_t pos) {
         uint32_t c = 0;
 #pragma unroll
@@ -488,18 +532,20 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
         return c;
       };
       uint32_t const low_mask = (1u << shift) - 1u;
+      // this piece's share of the unit's passes
+      uint32_t const n_pass = (rend + kPass - 1) / kPass;
+      uint32_t const pb_lo  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * piece / n_pc) * kPass;
+      uint32_t const pb_hi  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * (piece + 1) / n_pc) * kPass;
       // One pass of the workgroup covers THREADS * EPL entries, EPL per lane; entry e of lane tid is
       // pb + e * THREADS + tid, so that the 64 lanes of one gather instruction hold 64 CONSECUTIVE
       // entries (ascending sources: few cache lines per instruction).  The loop is software
       // pipelined: the entries of pass i+1 are requested right after the gathers of pass i were
-      // issued, so their HBM latency hides behind the gathers instead of adding to them (vector
-      // memory returns in order: gathers first, then the prefetch).  FAST: all entries of the pass
-      // exist and lie in one window (decided on uniform values), so no per-entry predicates.
+      // issued.  Loads carry no predicates (a branch around a load defeats the compiler's vmcnt
+      // bookkeeping): positions past the unit's end are clamped to its last entry and ignored.
+      // FAST: all entries of the pass exist and lie in one window (decided on uniform values).
+      uint32_t const q_last = (rend > 0 ? rend : 1u) - 1u;
       uint32_t en[EPL];
       ValT w[EPL];
-      // loads without predicates (a branch around a load defeats the compiler's vmcnt bookkeeping):
-      // positions past the unit's end are clamped to its last entry and ignored by the pass
-      uint32_t const q_last = (rend > 0 ? rend : 1u) - 1u;
       auto fetch = [&](uint32_t pb, uint32_t* en_out, ValT* w_out) {
         uint32_t const pos = pb + static_cast<uint32_t>(tid);
 #pragma unroll
@@ -526,30 +572,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           uint32_t gi = ((loc[e] & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc[e] & low_mask);
-          if constexpr (EXP == 3 || EXP == 4)
-            xv[e] = p[e] ? static_cast<ValT>(gi) : ValT(0);
-          else
-            xv[e] = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
-        }
-        if constexpr (EXP == 6) {
-          uint32_t const n_ent = rend - rbeg;
-          int const tc = n_ent < 16384u ? 0 : n_ent < 65536u ? 1 : n_ent < 262144u ? 2 : 3;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            uint32_t line = p[e] ? (loc[e] >> 5) : 0xFFFFFFFFu;
-            uint32_t prev = __shfl_up(line, 1);
-            bool first    = p[e] && ((tid & 63) == 0 || prev != line);
-            int sc        = loc[e] < 32768u ? 0 : loc[e] < 524288u ? 1 : 2;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              unsigned long long g = __popcll(__ballot(p[e] && sc == c));
-              unsigned long long l = __popcll(__ballot(first && sc == c));
-              if ((tid & 63) == 0 && g) {
-                atomicAdd(&xs_prof_buf[(tc * 3 + c) * 2], g);
-                atomicAdd(&xs_prof_buf[(tc * 3 + c) * 2 + 1], l);
-              }
-            }
-          }
+          xv[e]       = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
         }
         uint32_t en_next[EPL];
         ValT w_next[EPL];
@@ -558,10 +581,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
 #pragma unroll
           for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
         }
-        if constexpr (EXP == 1 || EXP == 4) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) racc[en[e] & 3] += static_cast<double>(xv[e]);
-        } else if (few) {
+        if (few) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             double v    = p[e] ? static_cast<double>(xv[e]) : 0.0;
@@ -580,45 +600,55 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
           if constexpr (WEIGHTED) w[e] = w_next[e];
         }
       };
-      if constexpr (EXP == 5) { pt_b = wall_clock64(); pt_setup += pt_b - pt_a; pt_n++; pt_stolen += rot != 0; }
-      fetch(0u, en, w);
-      for (uint32_t pb = 0; pb < rend; pb += kPass) {
+      if constexpr (PROFILE) { pt_b = wall_clock64(); pt_setup += pt_b - pt_a; pt_n++; pt_stolen += rot != 0; }
+      fetch(pb_lo, en, w);
+      int64_t r_next = -1;
+      int stage      = 0;  // 1: next item asked for, 2: its record requested
+      auto look_ahead = [&]() {
+        if (stage == 0) {
+          if (wave0 && lane == 0) q_next = atomicAdd(&xs.counters[k], 1);
+          stage = 1;
+        } else if (stage == 1) {
+          if (wave0) r_next = load_record(k, __shfl(q_next, 0));
+          stage = 2;
+        }
+      };
+      for (uint32_t pb = pb_lo; pb < pb_hi; pb += kPass) {
         uint32_t const w_lo = window_of(pb), w_hi = window_of(pb + kPass - 1);
         if (pb >= rbeg && pb + kPass <= rend && w_lo == w_hi)
           pass(std::true_type{}, pb, w_lo);
         else
           pass(std::false_type{}, pb, 0u);
+        if (pb + 3 * kPass >= pb_hi) look_ahead();
       }
-      if constexpr (EXP == 5) { pt_a = wall_clock64(); pt_pass += pt_a - pt_b; }
-      if (few || EXP == 1 || EXP == 4) {
+      look_ahead();
+      look_ahead();
+      if constexpr (PROFILE) { pt_a = wall_clock64(); pt_pass += pt_a - pt_b; }
+      if (few) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           double v = group_sum(racc[rr], 64);
-          if ((tid & 63) == 0 && rr < rows) atomicAdd(&acc[rr], static_cast<XsAcc>(v));
+          if (lane == 0 && rr < rows) atomicAdd(&acc[rr], v);
         }
       }
       __syncthreads();
-      ValT* out = xs.partial + (int64_t)k * xs.n_rows + row0;
-      for (int i = tid; i < rows; i += THREADS)
+      for (int i = tid; i < rows; i += THREADS) {
         __builtin_nontemporal_store(static_cast<ValT>(acc[i]), out + i);
+        acc[i] = 0;
+      }
+      if (wave0 && lane < kXsRecWords) s_rec[buf ^ 1][lane] = r_next;
+      buf ^= 1;
       __syncthreads();
-      if constexpr (EXP == 5) pt_wb += wall_clock64() - pt_a;
+      if constexpr (PROFILE) pt_wb += wall_clock64() - pt_a;
     }
   }
-  if constexpr (EXP == 5) {
+  if constexpr (PROFILE) {
     if (tid == 0 && blockIdx.x < 1024) {
       unsigned long long* o = xs_prof_buf + 8 * blockIdx.x;
       o[0] = my; o[1] = wall_clock64() - pt_t0; o[2] = pt_setup; o[3] = pt_pass; o[4] = pt_wb; o[5] = pt_n; o[6] = pt_stolen;
       o[7] = pt_t0;
     }
   }
-}
-
-void* xs_prof_ptr()
-{
-  void* ptr = nullptr;
-  CGA_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(xs_prof_buf)));
-  return ptr;
 }
 
 __global__ void xs_prof_dump_kernel(int n)
@@ -669,22 +699,92 @@ __global__ __launch_bounds__(kThreads) void hub_finish_kernel(IterArgs<OffT, Val
   write_partials(ep.dangling, ep.delta, partials);
 }
 
-// epilogue of the XS rows: the 8 per-slice partials of a row, added in a fixed order
+// epilogue of the XS rows: the partials of a row (one per slice and piece of its tile), added in a
+// fixed order.  A work item is a run of up to 512 rows of one tile; its record (4 words, one
+// scalar load): first row relative to row_first, rows in the run | partials per row << 32,
+// offset of the run's first partial, rows of the tile (= stride between partials of a row).
+constexpr int kXsFinishRows = 512;
 template <typename OffT, typename ValT>
 __global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT> a,
+                                                             int64_t const* __restrict__ fin_items,
+                                                             int n_fin_items,
                                                              double* __restrict__ partials)
 {
   if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
   Epilogue<OffT, ValT> ep(a);
   XsArgs<ValT> const& xs = a.xs;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < xs.n_rows;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    double s = 0.0;
+  for (int it = blockIdx.x; it < n_fin_items; it += gridDim.x) {
+    int64_t const* r  = fin_items + 4 * static_cast<int64_t>(it);
+    int64_t const row = xs.row_first + r[0];
+    int const count   = static_cast<int>(r[1] & 0xffffffff);
+    int const m       = static_cast<int>(r[1] >> 32);  // 8 * pieces
+    ValT const* p0    = xs.partial + r[2];
+    int64_t const stride = r[3];
+    // two rows per thread and eight partials per row at a time (m is a multiple of 8), so that
+    // the loads of a step are in flight together
+    int const i0  = threadIdx.x;
+    int const i1  = i0 + kThreads;
+    bool const h0 = i0 < count, h1 = i1 < count;
+    // loads without predicates (rows past the run's end re-read its last row and are dropped)
+    int const c0 = h0 ? i0 : count - 1, c1 = h1 ? i1 : count - 1;
+    double s0 = 0.0, s1 = 0.0;
+    for (int j = 0; j < m; j += kXsSlices) {
+      ValT v0[kXsSlices], v1[kXsSlices];
 #pragma unroll
-    for (int k = 0; k < kXsSlices; ++k) s += static_cast<double>(xs.partial[(int64_t)k * xs.n_rows + i]);
-    ep.finish(xs.row_first + i, static_cast<ValT>(s));
+      for (int u = 0; u < kXsSlices; ++u) {
+        ValT const* pj = p0 + (j + u) * stride;
+        v0[u]          = pj[c0];
+        v1[u]          = pj[c1];
+      }
+#pragma unroll
+      for (int u = 0; u < kXsSlices; ++u) {
+        s0 += static_cast<double>(v0[u]);
+        s1 += static_cast<double>(v1[u]);
+      }
+    }
+    if (h0) ep.finish(row + i0, static_cast<ValT>(s0));
+    if (h1) ep.finish(row + i1, static_cast<ValT>(s1));
   }
   write_partials(ep.dangling, ep.delta, partials);
+}
+
+// edges of every tile (for the host, which cuts big tiles into pieces)
+template <typename OffT>
+__global__ void xs_tile_edges_kernel(OffT const* __restrict__ offsets, int64_t row_first,
+                                     int32_t const* __restrict__ tile_row, int n_tiles,
+                                     int64_t* __restrict__ out)
+{
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += gridDim.x * blockDim.x)
+    out[t] = static_cast<int64_t>(offsets[row_first + tile_row[t + 1]]) -
+             static_cast<int64_t>(offsets[row_first + tile_row[t]]);
+}
+
+// One record per (slice, work item): what xs_kernel needs to start on that piece of the unit.
+//  [0] tile | piece << 32 | pieces << 40   [1] first row | rows << 32   [2] offset of its partials
+//  [3] first entry  [4] end of the unit's entries  [5..11] start of windows 1..7 (INT64_MAX: none)
+__global__ void xs_records_kernel(uint32_t const* __restrict__ items, int n_items,
+                                  int32_t const* __restrict__ tile_row,
+                                  int64_t const* __restrict__ unit_off,
+                                  int64_t const* __restrict__ pbase, int n_win,
+                                  int64_t* __restrict__ rec)
+{
+  int64_t total = static_cast<int64_t>(kXsSlices) * n_items;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int k = static_cast<int>(i / n_items), q = static_cast<int>(i % n_items);
+    uint32_t it = items[q];
+    int64_t t = it >> 8, piece = (it >> 4) & 15, n_pc = it & 15;
+    int64_t row0 = tile_row[t], rows = tile_row[t + 1] - row0;
+    int64_t u0 = (t * kXsSlices + k) * n_win;
+    int64_t* r = rec + i * kXsRecWords;
+    r[0] = t | (piece << 32) | (n_pc << 40);
+    r[1] = row0 | (rows << 32);
+    r[2] = pbase[t] + (k * n_pc + piece) * rows;
+    r[3] = unit_off[u0];
+    r[4] = unit_off[u0 + n_win];
+    for (int w = 1; w < 8; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
+    for (int w = 12; w < kXsRecWords; ++w) r[w] = 0;
+  }
 }
 
 // ---- XS build: unit id (tile * 8 + slice) and row of every edge of the XS row range
@@ -1087,9 +1187,10 @@ struct PullPlan {
   // XS tiles over the rows of buckets 1 and 2 (only on a degree-sorted compute graph)
   bool xs_on{false};
   int64_t xs_row_first{0}, xs_n_rows{0}, xs_n_edges{0};
-  int xs_n_tiles{0};
+  int xs_n_tiles{0}, xs_n_items{0}, xs_n_fin_items{0};
+  int64_t xs_partial_len{0};
   int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
-  DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row;
+  DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec, xs_pbase, xs_fin_items;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
   int64_t n_hub_items{0};
@@ -1174,12 +1275,11 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int64_t min_edges   = min_env ? std::atoll(min_env) : (int64_t(1) << 22);
   if (ne < min_edges || ne == 0 || ne > 0xffffffffLL) return;
   char const* te_env  = std::getenv("CUGRAPH_AMD_XS_TILE_EDGES");
-  // Tile size follows the graph: about 128 full-size tiles (1024 (tile, slice) units, one per
-  // resident workgroup), so that a small graph still fills the chip; capped at kXsTileEdges,
-  // where bigger tiles stop paying.  Measured (ms per iteration, best tile): scale 20 0.15 at
-  // 128 K, scale 22 0.24 at 0.5-1 M, scale 24 0.66 at 2 M, scale 26 2.85 at 8 M.
+  // Tile size follows the graph: big tiles gather from fewer distinct cache lines (scale 26: xs_kernel
+  // 2.32 ms at 8 M edges, 2.17 at 16 M, 2.13 at 64 M) but a small graph still needs enough of them to
+  // fill the chip.  Small scales are flat in both knobs (scale 22: 0.235 ms from 1 M to 4 M).
   int64_t tile_edges = kXsTileEdges;
-  while (tile_edges > (int64_t(1) << 16) && tile_edges * 128 > ne) tile_edges >>= 1;
+  while (tile_edges > (int64_t(1) << 16) && tile_edges * 32 > ne) tile_edges >>= 1;
   if (te_env) tile_edges = std::atoll(te_env);
   char const* sh_env  = std::getenv("CUGRAPH_AMD_XS_SLICE_SHIFT");
   int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
@@ -1251,6 +1351,60 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     std::fprintf(stderr, "xs verify: tiles %d n_win %d units %lld non-empty %llu entries %lld descending pairs %llu equal pairs %llu\n",
                  n_tiles, n_win, (long long)n_units, h[2], (long long)ne, h[0], h[1]);
   }
+  // ---- work items: a big tile is cut into pieces (runs of passes of each of its 8 units) so that
+  // no item is much longer than the rest; every (slice, piece) writes partials of its own
+  char const* pc_env     = std::getenv("CUGRAPH_AMD_XS_PIECE");
+  // small graphs: shorter pieces, so that there are a few thousand of them
+  int64_t piece_entries  = kXsPieceEntries;
+  while (piece_entries > (int64_t(1) << 15) && piece_entries * 4096 > ne) piece_entries >>= 1;
+  if (pc_env) piece_entries = std::atoll(pc_env);
+  DevBuf tile_ne(static_cast<size_t>(n_tiles) * 8);
+  hipLaunchKernelGGL((xs_tile_edges_kernel<OffT>), dim3(grid_for(n_tiles)), dim3(kThreads), 0, stream,
+                     offsets, row_first, plan.xs_tile_row.as<int32_t>(), n_tiles, tile_ne.as<int64_t>());
+  std::vector<int64_t> h_ne(n_tiles);
+  std::vector<int32_t> h_row(n_tiles + 1);
+  CGA_HIP(hipMemcpyAsync(h_ne.data(), tile_ne.p, static_cast<size_t>(n_tiles) * 8, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipMemcpyAsync(h_row.data(), plan.xs_tile_row.p, static_cast<size_t>(n_tiles + 1) * 4,
+                         hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  std::vector<uint32_t> h_items;
+  std::vector<int64_t> h_fin;
+  std::vector<int64_t> h_pbase(n_tiles + 1);
+  int64_t plen = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    int64_t per_unit = h_ne[t] / kXsSlices;
+    int64_t n_pc     = std::min<int64_t>(15, std::max<int64_t>(1, (per_unit + piece_entries / 2) / piece_entries));
+    for (int64_t j = 0; j < n_pc; ++j)
+      h_items.push_back(static_cast<uint32_t>(t) << 8 | static_cast<uint32_t>(j) << 4 | static_cast<uint32_t>(n_pc));
+    h_pbase[t] = plen;
+    plen += static_cast<int64_t>(kXsSlices) * n_pc * (h_row[t + 1] - h_row[t]);
+    int64_t const rows_t = h_row[t + 1] - h_row[t];
+    for (int64_t r = 0; r < rows_t; r += kXsFinishRows) {
+      h_fin.push_back(h_row[t] + r);
+      h_fin.push_back(std::min<int64_t>(kXsFinishRows, rows_t - r) | (kXsSlices * n_pc) << 32);
+      h_fin.push_back(h_pbase[t] + r);
+      h_fin.push_back(rows_t);
+    }
+  }
+  h_pbase[n_tiles] = plen;
+  if (n_tiles >= (1 << 24) || h_items.size() >= 0x7fffffffu / kXsSlices) return;
+  int n_items = static_cast<int>(h_items.size());
+  DevBuf items(static_cast<size_t>(n_items) * 4);
+  plan.xs_pbase.alloc(static_cast<size_t>(n_tiles + 1) * 8);
+  plan.xs_rec.alloc(static_cast<size_t>(kXsSlices) * n_items * kXsRecWords * 8);
+  CGA_HIP(hipMemcpyAsync(items.p, h_items.data(), items.bytes, hipMemcpyHostToDevice, stream));
+  CGA_HIP(hipMemcpyAsync(plan.xs_pbase.p, h_pbase.data(), plan.xs_pbase.bytes, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(xs_records_kernel, dim3(grid_for(static_cast<int64_t>(kXsSlices) * n_items)),
+                     dim3(kThreads), 0, stream, items.as<uint32_t>(), n_items,
+                     plan.xs_tile_row.as<int32_t>(), plan.xs_unit_off.as<int64_t>(),
+                     plan.xs_pbase.as<int64_t>(), n_win, plan.xs_rec.as<int64_t>());
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
+  plan.xs_fin_items.alloc(h_fin.size() * 8);
+  CGA_HIP(hipMemcpy(plan.xs_fin_items.p, h_fin.data(), h_fin.size() * 8, hipMemcpyHostToDevice));
+  plan.xs_n_fin_items = static_cast<int>(h_fin.size() / 4);
+  plan.xs_n_items     = n_items;
+  plan.xs_partial_len = plen;
   plan.xs_on        = true;
   plan.xs_row_first = row_first;
   plan.xs_n_rows    = n_rows;
@@ -1445,12 +1599,12 @@ int session_geometry(Session& s, PullPlan& plan)
   if (s.xs_on) {
     char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
     int want       = xb ? std::atoi(xb) : 1024;  // 4 workgroups (LDS-bound) on each of 256 CUs
-    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_tiles) * kXsSlices, want));
+    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_items) * kXsSlices, want));
   }
   if (s.xs_on) {
-    s.xs_partial.alloc(static_cast<size_t>(kXsSlices * plan.xs_n_rows) * vb);
+    s.xs_partial.alloc(static_cast<size_t>(plan.xs_partial_len) * vb);
     s.xs_counters.alloc(256);
-    s.n_xs_finish_blocks = grid_for(plan.xs_n_rows, 1024);
+    s.n_xs_finish_blocks = std::min(plan.xs_n_fin_items, 4096);
   }
   s.n_spmv_blocks = std::max(begin, 1);
   s.n_hub_items   = s.buckets[0].count > 0 ? plan.n_hub_items : 0;
@@ -1676,8 +1830,6 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   a.hub_items        = s.hub_items;
   a.n_hub_items      = s.n_hub_items;
   a.hub_item_partial = s.hub_item_partial.as<double>();
-  a.xs.block_begin   = s.xs_block_begin;
-  a.xs.n_blocks      = s.n_xs_blocks;
   {
     char const* am      = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
     a.xs.affinity_mode = am ? std::atoi(am) : 0;
@@ -1691,6 +1843,9 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.w         = plan.xs_w.p ? plan.xs_w.as<ValT>() : nullptr;
     a.xs.unit_off  = plan.xs_unit_off.as<int64_t>();
     a.xs.tile_row  = plan.xs_tile_row.as<int32_t>();
+    a.xs.rec       = plan.xs_rec.as<int64_t>();
+    a.xs.pbase     = plan.xs_pbase.as<int64_t>();
+    a.xs.n_items   = plan.xs_n_items;
     a.xs.partial   = s.xs_partial.as<ValT>();
     a.xs.counters  = s.xs_counters.as<int>();
     a.xs.row_first = plan.xs_row_first;
@@ -1702,53 +1857,22 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
   if (s.xs_on && s.n_xs_blocks > 0) {
-    auto launch_xs = [&](auto weighted_tag, auto threads_tag, auto bits_tag, auto exp_tag) {
+    static bool const profile = std::getenv("CUGRAPH_AMD_XS_PROFILE") != nullptr;
+    auto launch_xs = [&](auto weighted_tag, auto profile_tag) {
       constexpr bool W  = decltype(weighted_tag)::value;
-      constexpr int T   = decltype(threads_tag)::value;
-      constexpr int RB  = decltype(bits_tag)::value;
-      constexpr size_t lds = sizeof(double) << RB;
-      auto kern = xs_kernel<OffT, ValT, W, T, RB, decltype(exp_tag)::value>;
-      if (lds > 48 * 1024)
-        CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-      hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(T), lds, stream, a);
+      constexpr size_t lds = sizeof(double) << kXsRowBits;
+      auto kern = xs_kernel<OffT, ValT, W, kThreads, kXsRowBits, decltype(profile_tag)::value>;
+      hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(kThreads), lds, stream, a);
     };
-    char const* xt = std::getenv("CUGRAPH_AMD_XS_THREADS");
-    int xs_threads = xt ? std::atoi(xt) : kThreads;
-    auto by_bits = [&](auto weighted_tag) {
-      if (xs_threads == 512)
-        launch_xs(weighted_tag, std::integral_constant<int, 512>{}, std::integral_constant<int, kXsRowBits>{},
-                  std::integral_constant<int, 0>{});
-      else
-        launch_xs(weighted_tag, std::integral_constant<int, kThreads>{}, std::integral_constant<int, kXsRowBits>{},
-                  std::integral_constant<int, 0>{});
-    };
-    char const* ex = std::getenv("CUGRAPH_AMD_XS_EXP");
-    int exp_mode   = ex ? std::atoi(ex) : 0;
-    if constexpr (std::is_same_v<ValT, float> && std::is_same_v<OffT, int32_t>) {
-      if (!g.weights && exp_mode > 0) {
-        auto go = [&](auto m) {
-          launch_xs(std::false_type{}, std::integral_constant<int, kThreads>{},
-                    std::integral_constant<int, kXsRowBits>{}, m);
-        };
-        if (exp_mode == 1) go(std::integral_constant<int, 1>{});
-        if (exp_mode == 2) go(std::integral_constant<int, 2>{});
-        if (exp_mode == 3) go(std::integral_constant<int, 3>{});
-        if (exp_mode == 4) go(std::integral_constant<int, 4>{});
-        if (exp_mode == 6) {
-          if (s.enqueued == 3) CGA_HIP(hipMemsetAsync(xs_prof_ptr(), 0, 1024 * 64, stream));
-          go(std::integral_constant<int, 6>{});
-          if (s.enqueued == 3) hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, 3);
-        }
-        if (exp_mode == 5) {
-          go(std::integral_constant<int, 5>{});
-          if (s.enqueued == 3) hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, std::min(s.n_xs_blocks, 1024));
-        }
-      } else if (g.weights) by_bits(std::true_type{});
-      else by_bits(std::false_type{});
-    } else
-    if (g.weights) by_bits(std::true_type{});
-    else by_bits(std::false_type{});
+    if (profile && !g.weights) {
+      launch_xs(std::false_type{}, std::true_type{});
+      if (s.enqueued == 3)
+        hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, std::min(s.n_xs_blocks, 1024));
+    } else if (g.weights) {
+      launch_xs(std::true_type{}, std::false_type{});
+    } else {
+      launch_xs(std::false_type{}, std::false_type{});
+    }
   }
   // the dominant kernel: xs_kernel when the graph has XS tiles, else spmv_kernel
   if (ev_kernel_end && s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
@@ -1764,7 +1888,8 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
                        stream, a, s.hub_row_item_off, s.partials.as<double>() + 2 * s.n_spmv_blocks);
   if (s.n_xs_finish_blocks > 0)
     hipLaunchKernelGGL((xs_finish_kernel<OffT, ValT>), dim3(s.n_xs_finish_blocks), dim3(kThreads), 0,
-                       stream, a, s.partials.as<double>() + 2 * (s.n_spmv_blocks + s.n_hub_blocks));
+                       stream, a, s.graph->plan->xs_fin_items.as<int64_t>(), s.graph->plan->xs_n_fin_items,
+                       s.partials.as<double>() + 2 * (s.n_spmv_blocks + s.n_hub_blocks));
   if (raw_y) {
     CGA_HIP(hipGetLastError());
     return;
