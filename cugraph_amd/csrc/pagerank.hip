@@ -193,10 +193,19 @@ struct Epilogue {
       a.raw_out[v] = weighted_sum;
       return;
     }
-    ValT pr = base + a.alpha * weighted_sum;
-    if (a.pers_dense) pr += teleport * a.pers_dense[v];
     ValT old = __builtin_nontemporal_load(a.pr_old + v);
     ValT ow  = __builtin_nontemporal_load(a.out_w + v);
+    finish(v, weighted_sum, old, ow);
+  }
+  // old rank and out-weight sum of v already loaded (callers that want those loads in flight early)
+  __device__ inline void finish(int64_t v, ValT weighted_sum, ValT old, ValT ow)
+  {
+    if (a.raw_out) {
+      a.raw_out[v] = weighted_sum;
+      return;
+    }
+    ValT pr = base + a.alpha * weighted_sum;
+    if (a.pers_dense) pr += teleport * a.pers_dense[v];
     delta += fabs(static_cast<double>(pr) - static_cast<double>(old));
     ValT x = pr;
     if (ow == ValT(0)) {
@@ -311,23 +320,62 @@ __device__ inline void group_bucket(IterArgs<OffT, ValT> const& a, Bucket const&
   }
 }
 
-// thread per vertex, for the shortest columns (deg < 4)
+// thread per vertex, for the shortest columns (1 <= deg < kXsMinDegree).  Two rows per thread and
+// trip, every load of a step issued for both before anything waits: offsets -> the (up to) three
+// indices together with the row's old rank and out-weight -> the gathers.  Loads carry no
+// predicates: a position past the column's end re-reads its last edge and is dropped.
 template <typename OffT, typename ValT, bool WEIGHTED>
 __device__ inline void thread_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b,
                                      Epilogue<OffT, ValT>& ep)
 {
+  constexpr int D = static_cast<int>(kXsMinDegree) - 1;  // longest column of this bucket
+  constexpr int R = 2;
   int64_t t = (int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x;
   int64_t n = (int64_t)b.n_blocks * kThreads;
-  for (int64_t i = t; i < b.count; i += n) {
-    int64_t v = b.list ? static_cast<int64_t>(b.list[i]) : b.first + i;
-    OffT beg = a.offsets[v], end = a.offsets[v + 1];
-    ValT acc = 0;
-    for (OffT j = beg; j < end; ++j) {
-      ValT xv = a.x_cur[static_cast<uint32_t>(a.indices[j]) & a.gather_mask];
-      if constexpr (WEIGHTED) xv *= a.weights[j];
-      acc += xv;
+  bool const raw = a.raw_out != nullptr;
+  for (int64_t i = t; i < b.count; i += R * n) {
+    int64_t v[R];
+    bool have[R];
+    OffT beg[R], end[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t ir = i + r * n;
+      have[r]    = ir < b.count;
+      ir         = have[r] ? ir : i;
+      v[r]       = b.list ? static_cast<int64_t>(b.list[ir]) : b.first + ir;
+      beg[r]     = a.offsets[v[r]];
+      end[r]     = a.offsets[v[r] + 1];
     }
-    ep.finish(v, acc);
+    ValT old[R], ow[R];
+    uint32_t idx[R][D];
+    ValT w[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      old[r] = raw ? ValT(0) : __builtin_nontemporal_load(a.pr_old + v[r]);
+      ow[r]  = raw ? ValT(0) : __builtin_nontemporal_load(a.out_w + v[r]);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        OffT j    = beg[r] + d < end[r] ? beg[r] + d : end[r] - 1;
+        idx[r][d] = static_cast<uint32_t>(a.indices[j]);
+        if constexpr (WEIGHTED) w[r][d] = a.weights[j];
+      }
+    }
+    ValT xv[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int d = 0; d < D; ++d) xv[r][d] = a.x_cur[idx[r][d] & a.gather_mask];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ValT acc = 0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        ValT term = xv[r][d];
+        if constexpr (WEIGHTED) term *= w[r][d];
+        acc += beg[r] + d < end[r] ? term : ValT(0);
+      }
+      if (have[r]) ep.finish(v[r], acc, old[r], ow[r]);
+    }
   }
 }
 
@@ -1876,6 +1924,7 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   }
   // the dominant kernel: xs_kernel when the graph has XS tiles, else spmv_kernel
   if (ev_kernel_end && s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
+  // (spmv_kernel on a second stream beside xs_kernel was measured slower: 2.86 vs 2.74 ms)
   if (g.weights)
     hipLaunchKernelGGL((spmv_kernel<OffT, ValT, true>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
                        stream, a);

@@ -86,11 +86,15 @@ class PagerankSession:
             self._ptr, ctypes.byref(xv), ctypes.byref(sv), ctypes.byref(err))
         _capi.check(code, err, "cugraph_amd_pagerank_session_exchange_buffers")
         out = []
+        cache = self.__dict__.setdefault("_aliases", {})  # the two x buffers and the scalars never move
         for v in (xv, sv):
-            n = self._lib.cugraph_type_erased_device_array_view_size(v)
-            t = self._lib.cugraph_type_erased_device_array_view_type(v)
             p = self._lib.cugraph_type_erased_device_array_view_pointer(v)
-            out.append(_alias_device_memory(p, n, get_numpy_type_from_c_type(t)))
+            t = cache.get(p)
+            if t is None:
+                n = self._lib.cugraph_type_erased_device_array_view_size(v)
+                ty = self._lib.cugraph_type_erased_device_array_view_type(v)
+                t = cache[p] = _alias_device_memory(p, n, get_numpy_type_from_c_type(ty))
+            out.append(t)
             self._lib.cugraph_type_erased_device_array_view_free(v)
         return tuple(out)
 
