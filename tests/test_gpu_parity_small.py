@@ -175,6 +175,38 @@ def test_rmat_pagerank_vs_oracle(scale, dtype, weighted, xs_tiles, monkeypatch):
     assert abs(r.sum() - 1.0) < (1e-4 if dtype == np.float32 else 1e-10)
 
 
+@pytest.mark.parametrize("tile_edges,piece", [(65536, 1024), (1 << 30, 300), (4096, 1 << 20), (1 << 20, 1 << 14)])
+@pytest.mark.parametrize("scale,dtype,weighted", [(16, np.float32, False), (14, np.float64, True)])
+def test_xs_work_items_cut_into_pieces(tile_edges, piece, scale, dtype, weighted, monkeypatch):
+    """The XS work-item machinery at sizes a test can hold: tiles cut into up to 15 pieces (each
+    with partials of its own), one tile holding every row, tiles of a few rows -- all must give the
+    ranks of the C oracle (1e-6 fp32 / 1e-10 fp64 max-abs) in the same number of iterations."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0")
+    monkeypatch.setenv("CUGRAPH_AMD_XS_TILE_EDGES", str(tile_edges))
+    monkeypatch.setenv("CUGRAPH_AMD_XS_PIECE", str(piece))
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=7)
+    wgt = oracle.rmat_weights(ne, seed=8).astype(dtype) if weighted else None
+    g, h = make_sg_graph(src, dst, wgt, vertices=np.arange(nv, dtype=np.int32), multigraph=True,
+                         renumber=True)
+    eps = nv * 1e-8
+    v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, eps, 500, False,
+                              fail_on_nonconvergence=False)
+    o_off, o_idx, perm = oracle.compress(nv, dst, src)
+    o_pr, o_it, o_conv = oracle.pagerank(nv, o_off, o_idx, None if wgt is None else wgt[perm],
+                                         dtype=np.float64, alpha=0.85, epsilon=eps,
+                                         max_iterations=500)
+    assert conv and o_conv
+    got = np.empty(nv, dtype=np.float64)
+    got[v.cpu().numpy()] = r.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - o_pr)) <= (1e-6 if dtype == np.float32 else 1e-10)
+    top = np.argsort(-o_pr, kind="stable")[:100]
+    assert np.max(np.abs(got[top] - o_pr[top]) / o_pr[top]) <= (2e-5 if dtype == np.float32 else 1e-9)
+
+
 @pytest.mark.parametrize("name", ["karate.csv", "dolphins.csv", "netscience.csv"])
 @pytest.mark.parametrize("id_dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("transposed", [True, False])
