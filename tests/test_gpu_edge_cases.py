@@ -1,0 +1,120 @@
+"""Edge cases of the PageRank path through the C ABI, against the CPU oracle: degenerate graphs
+(no edges, one vertex, only self-loops, a star, every vertex dangling, zero weights), the limits
+of alpha and max_iterations (pagerank_impl.cuh:89-99, 328-337), personalization on vertices
+without edges, and empty optional arrays."""
+import numpy as np
+import pytest
+
+from helpers import make_sg_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(src, dst, wgt, nv, *, alpha=0.85, eps=1e-10, max_it=200, pers=None, renumber=False, dtype=np.float64):
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    src = np.asarray(src, np.int32)
+    dst = np.asarray(dst, np.int32)
+    w = None if wgt is None else np.asarray(wgt, dtype)
+    g, h = make_sg_graph(src, dst, w, vertices=np.arange(nv, dtype=np.int32), multigraph=True, renumber=renumber)
+    if pers is None:
+        v, r, conv = plc.pagerank(h, g, None, None, None, None, alpha, eps, max_it, False,
+                                  fail_on_nonconvergence=False)
+    else:
+        v, r, conv = plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.asarray(pers[0], np.int32)),
+                                               to_dev(np.asarray(pers[1], dtype if w is not None else np.float32)),
+                                               alpha, eps, max_it, False, fail_on_nonconvergence=False)
+    off, idx, perm = oracle.compress(nv, dst, src)
+    kw = {}
+    if pers is not None:
+        kw = dict(pers_vertices=pers[0], pers_values=pers[1])
+    o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, None if w is None else w[perm],
+                                         dtype=np.float64, alpha=alpha, epsilon=eps, max_iterations=max_it, **kw)
+    got = np.empty(nv, dtype=np.float64)
+    got[v.cpu().numpy()] = r.cpu().numpy().astype(np.float64)
+    return got, bool(conv), o_pr, o_conv
+
+
+@pytest.mark.parametrize("renumber", [False, True])
+@pytest.mark.parametrize("nv", [1, 5, 1000])
+def test_graph_without_edges(nv, renumber):
+    got, conv, ref, rconv = _run([], [], None, nv, renumber=renumber)
+    assert conv == rconv
+    assert np.allclose(got, 1.0 / nv, rtol=0, atol=1e-7)
+    assert np.max(np.abs(got - ref)) <= 1e-7
+
+
+@pytest.mark.parametrize("renumber", [False, True])
+def test_only_self_loops_and_one_vertex(renumber):
+    got, conv, ref, rconv = _run([0], [0], None, 1, renumber=renumber)
+    assert conv == rconv and abs(got[0] - ref[0]) <= 1e-7 and abs(got[0] - 1.0) <= 1e-6
+    got, conv, ref, rconv = _run([0, 1, 2, 2], [0, 1, 2, 2], None, 4, renumber=renumber)
+    assert conv == rconv
+    assert np.max(np.abs(got - ref)) <= 1e-7
+
+
+@pytest.mark.parametrize("renumber", [False, True])
+@pytest.mark.parametrize("n_leaves", [3, 70, 5000, 40000])
+def test_star_into_one_hub(n_leaves, renumber):
+    """every leaf points at vertex 0 (a single column longer than the hub thresholds at 40000),
+    which points back at leaf 1; the other vertices dangle"""
+    src = list(range(1, n_leaves + 1)) + [0]
+    dst = [0] * n_leaves + [1]
+    # unweighted graphs compute in fp32 (graph_sg.cpp:247): an epsilon fp32 can reach
+    got, conv, ref, rconv = _run(src, dst, None, n_leaves + 3, renumber=renumber, eps=1e-6)
+    assert conv and rconv
+    assert np.max(np.abs(got - ref)) <= 1e-6
+    assert abs(got.sum() - 1.0) <= 1e-4
+
+
+def test_zero_weights_make_a_vertex_dangle():
+    src, dst = [0, 0, 1, 2, 3], [1, 2, 2, 0, 0]
+    wgt = [0.0, 0.0, 1.0, 2.0, 0.5]  # vertex 0 has out-edges of weight 0: out-weight sum 0 -> dangling
+    got, conv, ref, rconv = _run(src, dst, wgt, 4)
+    assert conv == rconv
+    assert np.max(np.abs(got - ref)) <= 1e-10
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.5, 1.0])
+def test_alpha_limits(alpha):
+    from helpers import load_csv
+
+    src, dst, w = load_csv("karate.csv")
+    got, conv, ref, rconv = _run(src, dst, w.astype(np.float64), 34, alpha=alpha, eps=1e-9, max_it=300)
+    assert conv == rconv
+    assert np.max(np.abs(got - ref)) <= 1e-9
+    if alpha == 0.0:
+        assert np.allclose(got, 1.0 / 34, atol=1e-12)
+
+
+@pytest.mark.parametrize("max_it", [0, 1, 2])
+def test_iteration_limits(max_it):
+    """at least one iteration always runs and converged = iterations < max_iterations
+    (pagerank_impl.cuh:328-337)"""
+    from helpers import load_csv
+
+    src, dst, w = load_csv("karate.csv")
+    got, conv, ref, rconv = _run(src, dst, w.astype(np.float64), 34, eps=1e-12, max_it=max_it)
+    assert conv is False and rconv is False
+    assert np.max(np.abs(got - ref)) <= 1e-12
+
+
+def test_personalization_on_vertices_without_edges():
+    """personalization mass on an isolated vertex and on a dangling one; values not normalised"""
+    src, dst = [0, 1, 2, 2, 4], [1, 2, 0, 3, 2]  # 3 dangles, 5 and 6 are isolated
+    pers = ([5, 3, 0], [2.0, 0.5, 0.25])
+    got, conv, ref, rconv = _run(src, dst, [1.0, 2.0, 3.0, 1.0, 1.0], 7, pers=pers)
+    assert conv == rconv
+    assert np.max(np.abs(got - ref)) <= 1e-10
+    assert got[6] <= 1e-12 and got[5] > 0.1
+
+
+def test_empty_personalization_is_rejected():
+    from cugraph_amd import pylibcugraph as plc
+
+    g, h = make_sg_graph(np.array([0, 1], np.int32), np.array([1, 0], np.int32), None,
+                         vertices=np.arange(2, dtype=np.int32))
+    with pytest.raises((ValueError, RuntimeError)):
+        plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.zeros(0, np.int32)),
+                                  to_dev(np.zeros(0, np.float32)), 0.85, 1e-6, 100, False)
