@@ -48,7 +48,11 @@ constexpr int kXsSlices       = 8;      // one slice of the source ids per XCD
 constexpr int64_t kXsTileEdges = 1 << 26;  // a tile is a run of rows holding about this many edges,
 constexpr int kXsEntriesPerLane = 8;   // gathers a lane keeps in flight per pass
 constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longer (tile, slice) units are cut
-constexpr int kXsRowBits      = 12;       // a tile never has more than 2^12 rows (32 KiB of fp64 LDS accumulators)
+// rows per tile = fp64 LDS accumulators per workgroup: 2^12 (32 KiB, 256 threads, 4 workgroups per
+// CU), 2^13 (64 KiB, 512 threads, 2 per CU) or 2^14 (128 KiB, 1024 threads, 1 per CU) -- the widest
+// whose entry format still covers the source space with the windows a record carries
+constexpr int kXsRowBits      = 12;
+constexpr int kXsRowBitsMax   = 14;
 constexpr int kXsMinDegree    = 4;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
@@ -76,9 +80,9 @@ struct XsArgs {
   uint32_t const* ent;
   ValT const* w;             // [n_edges + 4] or nullptr
   int64_t const* unit_off;   // [n_tiles * 8 * n_win + 1]
-  // one 128-byte record per (slice, work item), see xs_records_kernel: everything a workgroup needs
+  // one 256-byte record per (slice, work item), see xs_records_kernel: everything a workgroup needs
   // to start on a piece of a (tile, slice) unit, fetched with one load behind the queue's atomic
-  int64_t const* rec;        // [8][n_items][16]
+  int64_t const* rec;        // [8][n_items][32]
   int64_t const* pbase;      // [n_tiles + 1] first partial of each tile (8 * pieces * rows per tile)
   int n_items;               // work items per slice queue: the pieces of all tiles, biggest tiles first
   int n_win;                 // windows of 2^(32 - row_bits) slice-local positions per slice
@@ -92,7 +96,8 @@ struct XsArgs {
   int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
 };
 
-constexpr int kXsRecWords = 16;
+constexpr int kXsRecWords   = 32;
+constexpr int kXsRegWindows = 16;  // window starts a record carries (kept in scalar registers)
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
 struct HubItem {
@@ -558,24 +563,24 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
       double racc[4] = {0.0, 0.0, 0.0, 0.0};
       int const shift = xs.slice_shift;
       // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
-      // from its position (boundaries relative to the aligned start; up to 8 kept in registers)
+      // from its position (boundaries relative to the aligned start; up to 16 kept in registers)
       int64_t const u0    = ((int64_t)t * kXsSlices + k) * xs.n_win;
       int64_t const beg   = uniform64(rec[3]);
       int64_t const end   = uniform64(rec[4]);
       int64_t const abeg  = beg & ~int64_t(3);
       uint32_t const rbeg = static_cast<uint32_t>(beg - abeg);
       uint32_t const rend = static_cast<uint32_t>(end - abeg);
-      uint32_t wb[8];
+      uint32_t wb[kXsRegWindows];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) {
+      for (int w = 1; w < kXsRegWindows; ++w) {
         int64_t d = uniform64(rec[4 + w]) - abeg;  // INT64_MAX for windows the graph does not have
         wb[w]     = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : static_cast<uint32_t>(d);
       }
       auto window_of = [&](uint32_t pos) {
         uint32_t c = 0;
 #pragma unroll
-        for (int w = 1; w < 8; ++w) c += pos >= wb[w] ? 1u : 0u;
-        for (int w = 8; w < xs.n_win; ++w)  // more than 2^26 vertices per slice
+        for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
+        for (int w = kXsRegWindows; w < xs.n_win; ++w)  // very large source spaces only
           c += pos >= static_cast<uint32_t>(xs.unit_off[u0 + w] - abeg) ? 1u : 0u;
         return c;
       };
@@ -809,7 +814,7 @@ __global__ void xs_tile_edges_kernel(OffT const* __restrict__ offsets, int64_t r
 
 // One record per (slice, work item): what xs_kernel needs to start on that piece of the unit.
 //  [0] tile | piece << 32 | pieces << 40   [1] first row | rows << 32   [2] offset of its partials
-//  [3] first entry  [4] end of the unit's entries  [5..11] start of windows 1..7 (INT64_MAX: none)
+//  [3] first entry  [4] end of the unit's entries  [5..19] start of windows 1..15 (INT64_MAX: none)
 __global__ void xs_records_kernel(uint32_t const* __restrict__ items, int n_items,
                                   int32_t const* __restrict__ tile_row,
                                   int64_t const* __restrict__ unit_off,
@@ -830,8 +835,8 @@ __global__ void xs_records_kernel(uint32_t const* __restrict__ items, int n_item
     r[2] = pbase[t] + (k * n_pc + piece) * rows;
     r[3] = unit_off[u0];
     r[4] = unit_off[u0 + n_win];
-    for (int w = 1; w < 8; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
-    for (int w = 12; w < kXsRecWords; ++w) r[w] = 0;
+    for (int w = 1; w < kXsRegWindows; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
+    for (int w = 4 + kXsRegWindows; w < kXsRecWords; ++w) r[w] = 0;
   }
 }
 
@@ -1333,7 +1338,19 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
   // 13 / 14 (512- / 1024-thread workgroups, 64 / 128 KiB of accumulators, tiles of up to 8192 /
   // 16384 rows) were measured at scale 26: 3.8 / 7.0 ms against 2.3 ms for 12 -- kept at 12
-  int const row_bits  = kXsRowBits;
+  // Rows per tile: as many as the entry format allows.  An entry keeps 32 - row_bits bits of its
+  // source position, the rest is implied by its window, and a record carries 16 window starts: 2^14
+  // rows reach 33 M source ids (or slots), 2^13 rows 67 M, 2^12 rows 134 M (beyond: more windows,
+  // read from memory).  Twice the rows per tile = twice the entries per (tile, slice) unit over the
+  // same sources, so fewer distinct lines per gather instruction, and half the tiles.  Measured
+  // (xs_kernel, 12 / 13 / 14 bits): scale 22 0.190 / 0.146 / 0.129 ms, scale 24 0.503 / 0.457 /
+  // 0.438, scale 26 with compact slots (multi-GPU layout) 2.14 / 1.96 / 1.86.
+  char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
+  uint32_t const last_local = xs_slice_local(static_cast<uint32_t>(g.minor_space() - 1), slice_shift) |
+                              ((1u << slice_shift) - 1u);
+  int row_bits = kXsRowBitsMax;
+  while (row_bits > kXsRowBits && (last_local >> (32 - row_bits)) >= static_cast<uint32_t>(kXsRegWindows)) --row_bits;
+  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
@@ -1402,9 +1419,11 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // ---- work items: a big tile is cut into pieces (runs of passes of each of its 8 units) so that
   // no item is much longer than the rest; every (slice, piece) writes partials of its own
   char const* pc_env     = std::getenv("CUGRAPH_AMD_XS_PIECE");
-  // small graphs: shorter pieces, so that there are a few thousand of them
-  int64_t piece_entries  = kXsPieceEntries;
-  while (piece_entries > (int64_t(1) << 15) && piece_entries * 4096 > ne) piece_entries >>= 1;
+  // a piece is 64 passes of its workgroup (128 of a 256-thread one); small graphs: down to 16, so
+  // that there are a few thousand pieces
+  int64_t const pass_entries = int64_t(kThreads * kXsEntriesPerLane) << (row_bits - kXsRowBits);
+  int64_t piece_entries      = row_bits == kXsRowBits ? kXsPieceEntries : 64 * pass_entries;
+  while (piece_entries > 16 * pass_entries && piece_entries * 1024 > ne) piece_entries >>= 1;
   if (pc_env) piece_entries = std::atoll(pc_env);
   DevBuf tile_ne(static_cast<size_t>(n_tiles) * 8);
   hipLaunchKernelGGL((xs_tile_edges_kernel<OffT>), dim3(grid_for(n_tiles)), dim3(kThreads), 0, stream,
@@ -1646,7 +1665,8 @@ int session_geometry(Session& s, PullPlan& plan)
   s.n_xs_blocks    = 0;
   if (s.xs_on) {
     char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
-    int want       = xb ? std::atoi(xb) : 1024;  // 4 workgroups (LDS-bound) on each of 256 CUs
+    // as many workgroups as are resident at once (LDS-bound): 4 of 256 threads, 2 of 512 or 1 of 1024 per CU
+    int want       = xb ? std::atoi(xb) : 1024 >> (plan.xs_row_bits - kXsRowBits);
     s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_items) * kXsSlices, want));
   }
   if (s.xs_on) {
@@ -1908,6 +1928,21 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     static bool const profile = std::getenv("CUGRAPH_AMD_XS_PROFILE") != nullptr;
     auto launch_xs = [&](auto weighted_tag, auto profile_tag) {
       constexpr bool W  = decltype(weighted_tag)::value;
+      auto wide = [&](auto bits_tag) {
+        constexpr int RB     = decltype(bits_tag)::value;
+        constexpr int T      = kThreads << (RB - kXsRowBits);
+        constexpr size_t lds = sizeof(double) << RB;
+        auto kern = xs_kernel<OffT, ValT, W, T, RB, decltype(profile_tag)::value>;
+        static bool const raised = [&] {
+          return hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)) == hipSuccess;
+        }();
+        CGA_EXPECTS(raised, CUGRAPH_UNKNOWN_ERROR, "internal: cannot reserve the LDS of a wide XS tile");
+        hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(T), lds, stream, a);
+      };
+      if (a.xs.row_bits == 14) return wide(std::integral_constant<int, 14>{});
+      if (a.xs.row_bits == 13) return wide(std::integral_constant<int, 13>{});
       constexpr size_t lds = sizeof(double) << kXsRowBits;
       auto kern = xs_kernel<OffT, ValT, W, kThreads, kXsRowBits, decltype(profile_tag)::value>;
       hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(kThreads), lds, stream, a);
