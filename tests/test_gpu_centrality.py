@@ -92,6 +92,9 @@ def test_rmat_centralities_vs_oracle(scale, dtype, xs_tiles, renumber, monkeypat
     from cugraph_amd import pylibcugraph as plc
 
     monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0" if xs_tiles else str(1 << 40))
+    # the XS runs also take the compact source space big graphs get (the products then scatter
+    # their input vector to the slots)
+    monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1" if xs_tiles else "0")
     nv, ne = 1 << scale, 16 << scale
     src, dst = oracle.rmat_edges(scale, ne, seed=5, scramble=True)
     wgt = oracle.rmat_weights(ne, seed=6).astype(dtype)
