@@ -1,4 +1,4 @@
-"""Fold the rocprofv3 passes of tools/xs_exp3.sh (gpurun_out/) into profiles/<tag>_pmc_xs.{json,md} inputs:
+"""Fold the rocprofv3 passes of tools/pmc_passes.sh (gpurun_out/) into profiles/<tag>_pmc_xs.{json,md} inputs:
 per-launch averages of every counter for xs_kernel, plus the two calibration runs."""
 import csv, glob, json, sys, collections
 
