@@ -109,6 +109,7 @@ struct Ctrl {
   unsigned long long iters;
   int done;
   int pad;
+  double base_prev;  // rank every vertex without in-edges got in the last iteration (dead rows)
 };
 
 struct Bucket {
@@ -1021,11 +1022,36 @@ __global__ __launch_bounds__(kThreads) void pers_fix_kernel(
 }
 
 // one workgroup: fold the per-workgroup partials in a fixed order -> bitwise reproducible scalars
+// Dead rows (vertices no edge touches; the last n_dead rows of a degree-sorted graph) are not
+// visited after the first iteration: each gets the same rank `base`, so their share of the two
+// sums is added here.  base is recomputed exactly as Epilogue does, from the dangling mass the
+// iteration's kernels read.
+struct DeadRows {
+  int64_t n_dead;   // 0: nothing to add (no dead rows, or this iteration visited them)
+  int track;        // keep ctrl->base_prev up to date
+  int f64;
+  double alpha, one_minus_alpha, num_vertices;  // as the kernels hold them (already rounded to ValT)
+};
+
 __global__ __launch_bounds__(kThreads) void finalize_kernel(double const* __restrict__ partials,
                                                             int n_partials, double* scal, Ctrl* ctrl,
-                                                            double epsilon, int count_iteration)
+                                                            double epsilon, int count_iteration,
+                                                            DeadRows dead)
 {
   if (count_iteration && stop_check(ctrl, scal, epsilon, false)) return;
+  double dead_dangling = 0.0, dead_delta = 0.0, base = 0.0;
+  if (dead.track) {
+    if (dead.f64) {
+      double teleport = scal[0] * dead.alpha + dead.one_minus_alpha;
+      base            = teleport / dead.num_vertices;
+    } else {
+      float teleport = static_cast<float>(scal[0]) * static_cast<float>(dead.alpha) +
+                       static_cast<float>(dead.one_minus_alpha);
+      base           = static_cast<double>(teleport / static_cast<float>(dead.num_vertices));
+    }
+    dead_dangling = static_cast<double>(dead.n_dead) * base;
+    dead_delta    = static_cast<double>(dead.n_dead) * fabs(base - ctrl->base_prev);
+  }
   __shared__ double lds[2 * (kThreads / 64)];
   double d = 0.0, l = 0.0;
   for (int i = threadIdx.x; i < n_partials; i += kThreads) {
@@ -1045,10 +1071,11 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(double const* __rest
       ds += lds[2 * w];
       ls += lds[2 * w + 1];
     }
-    scal[0] = ds;
+    scal[0] = ds + dead_dangling;
     if (count_iteration) {
-      scal[1] = ls;
+      scal[1] = ls + dead_delta;
       ctrl->iters += 1;
+      if (dead.track) ctrl->base_prev = base;
     } else {
       scal[1] = 1e300;  // "no previous iteration": never below epsilon, survives an 8-rank sum
     }
@@ -1245,6 +1272,7 @@ struct PullPlan {
   // of the compute graph (same offsets and weights, NOT owned) whose indices are slots and whose
   // x_pos maps a row to its slot.  nullptr: every source is addressed by its vertex id.
   Graph* compact{nullptr};
+  int64_t n_dead{0};  // rows at the very end without in-edges and without a slot (no edge touches them)
   DevBuf lists[kNumBuckets];
   int64_t counts[kNumBuckets]{};
   int64_t firsts[kNumBuckets]{};
@@ -1504,6 +1532,23 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_row_bits  = row_bits;
 }
 
+template <typename OffT>
+__global__ void dead_rows_kernel(OffT const* __restrict__ offsets, int32_t const* __restrict__ x_pos,
+                                 int64_t n, unsigned long long* __restrict__ out /* {count, first} */)
+{
+  unsigned long long cnt = 0, first = ~0ull;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n;
+       v += (int64_t)gridDim.x * blockDim.x)
+    if (offsets[v + 1] == offsets[v] && x_pos[v] < 0) {
+      ++cnt;
+      if (static_cast<unsigned long long>(v) < first) first = static_cast<unsigned long long>(v);
+    }
+  if (cnt) {
+    atomicAdd(&out[0], cnt);
+    atomicMin(&out[1], first);
+  }
+}
+
 __global__ void mark_sources_kernel(int32_t const* __restrict__ indices, int64_t n_edges,
                                     unsigned int* __restrict__ flags)
 {
@@ -1582,6 +1627,24 @@ void build_compact(hipStream_t stream, Graph const& cg, PullPlan& plan)
   c->x_pos               = static_cast<int32_t*>(x_pos.detach());
   c->num_source_slots    = std::max<int64_t>(n_slots, 1);
   plan.compact           = c.release();
+  // dead rows: only if they are one run at the very end (a degree-sorted graph built here has
+  // them there: renumber.hip, degree_order_sources_first)
+  char const* dead_env = std::getenv("CUGRAPH_AMD_DEAD_ROWS");
+  if (!(dead_env && dead_env[0] == '0')) {
+    DevBuf out(16);
+    unsigned long long h_out[2] = {0ull, ~0ull};
+    CGA_HIP(hipMemcpyAsync(out.p, h_out, 16, hipMemcpyHostToDevice, stream));
+    if (cg.off64)
+      hipLaunchKernelGGL((dead_rows_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(cg.offsets), plan.compact->x_pos, n, out.as<unsigned long long>());
+    else
+      hipLaunchKernelGGL((dead_rows_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(cg.offsets), plan.compact->x_pos, n, out.as<unsigned long long>());
+    CGA_HIP(hipMemcpyAsync(h_out, out.p, 16, hipMemcpyDeviceToHost, stream));
+    CGA_HIP(hipStreamSynchronize(stream));
+    if (h_out[0] > 0 && h_out[1] + h_out[0] == static_cast<unsigned long long>(n))
+      plan.n_dead = static_cast<int64_t>(h_out[0]);
+  }
 }
 
 PullPlan& get_plan(Handle const& h, Graph& g)
@@ -1685,6 +1748,7 @@ struct Session {
   size_t enqueued{0};
   int n_spmv_blocks{0}, n_pers_blocks{0}, n_hub_blocks{0};
   bool xs_on{false};
+  int64_t n_dead{0};  // trailing rows no edge touches, skipped after the first iteration
   int xs_block_begin{0}, n_xs_blocks{0}, n_xs_finish_blocks{0};
   DevBuf xs_partial, xs_counters;
   int64_t n_hub_items{0};
@@ -1953,6 +2017,8 @@ void session_setup(Session& s, PagerankArgs const& a)
   }
 
   int n_prep_blocks = session_geometry<ValT>(s, plan);
+  // a personalized run gives a dead row its own rank (teleport * p_v): then they are all visited
+  s.n_dead = (!s.personalized && plan.contiguous && plan.n_dead <= s.buckets[4].count) ? plan.n_dead : 0;
 
   // ---- x0 and the dangling mass of pr0
   hipLaunchKernelGGL((prep_kernel<ValT>), dim3(n_prep_blocks), dim3(kThreads), 0, stream,
@@ -1960,7 +2026,7 @@ void session_setup(Session& s, PagerankArgs const& a)
                      s.x[0].as<ValT>(),
                      s.partials.as<double>());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, stream, s.partials.as<double>(),
-                     n_prep_blocks, s.scal.as<double>(), s.ctrl.as<Ctrl>(), s.epsilon, 0);
+                     n_prep_blocks, s.scal.as<double>(), s.ctrl.as<Ctrl>(), s.epsilon, 0, DeadRows{});
   CGA_HIP(hipGetLastError());
 }
 
@@ -2026,6 +2092,20 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     CGA_HIP(hipMemsetAsync(s.xs_counters.p, 0, 256, stream));
   }
   for (int b = 0; b < kNumBuckets; ++b) a.buckets[b] = s.buckets[b];
+  // dead rows (the tail of the isolated bucket): visited by the first iteration only, whose old
+  // ranks are the caller's; from then on finalize_kernel adds their share (see DeadRows)
+  DeadRows dead{};
+  if (s.n_dead > 0 && !raw_y) {
+    dead.track           = 1;
+    dead.f64             = s.f64 ? 1 : 0;
+    dead.alpha           = static_cast<double>(a.alpha);
+    dead.one_minus_alpha = static_cast<double>(a.one_minus_alpha);
+    dead.num_vertices    = static_cast<double>(a.num_vertices);
+    if (s.enqueued > 0) {
+      dead.n_dead = s.n_dead;
+      a.buckets[4].count -= s.n_dead;
+    }
+  }
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
   if (s.xs_on && s.n_xs_blocks > 0) {
@@ -2092,7 +2172,7 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, stream, s.partials.as<double>(),
                      s.n_spmv_blocks + s.n_hub_blocks + s.n_xs_finish_blocks + s.n_pers_blocks,
                      s.scal.as<double>(),
-                     s.ctrl.as<Ctrl>(), s.epsilon, 1);
+                     s.ctrl.as<Ctrl>(), s.epsilon, 1, dead);
   CGA_HIP(hipGetLastError());
   s.enqueued += 1;
 }
@@ -2208,6 +2288,21 @@ CentralityResult* session_result(Session& s, size_t max_iterations)
     if (s.n_local > 0) {
       CGA_HIP(hipMalloc(&vals->data, vals->nbytes));
       CGA_HIP(hipMalloc(&ids->data, ids->nbytes));
+      if (s.n_dead > 0 && iters >= 1) {
+        // the dead rows were last written by the first iteration: they hold the rank every vertex
+        // without in-edges got in the last one
+        Ctrl c{};
+        CGA_HIP(hipMemcpyAsync(&c, s.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+        CGA_HIP(hipStreamSynchronize(stream));
+        int64_t first = s.n_local - s.n_dead;
+        if (s.f64)
+          hipLaunchKernelGGL((fill_kernel<double>), dim3(grid_for(s.n_dead)), dim3(kThreads), 0, stream,
+                             s.pr[iters & 1].as<double>() + first, s.n_dead, c.base_prev);
+        else
+          hipLaunchKernelGGL((fill_kernel<float>), dim3(grid_for(s.n_dead)), dim3(kThreads), 0, stream,
+                             s.pr[iters & 1].as<float>() + first, s.n_dead, static_cast<float>(c.base_prev));
+        CGA_HIP(hipGetLastError());
+      }
       if (s.order) {  // ranks were computed on the degree-sorted copy: back to the graph's order
         int grid = grid_for(s.n_local);
         if (s.f64)

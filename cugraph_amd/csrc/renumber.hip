@@ -158,6 +158,44 @@ inline int bit_width_u32(unsigned int v)
 
 }  // namespace
 
+namespace {
+__global__ void mark_ids_kernel(int32_t const* __restrict__ ids, int64_t n, unsigned int* __restrict__ flags)
+{
+  GRID_STRIDE(i, n) { flags[ids[i]] = 1u; }
+}
+
+// sort key of a vertex: its major degree; among the vertices of degree 0 the ones that appear as
+// a minor (an edge leaves them in a transposed graph) come first
+__global__ void degree_keys_kernel(unsigned int const* __restrict__ deg, unsigned int const* __restrict__ is_minor,
+                                   int64_t n, unsigned int* __restrict__ keys)
+{
+  GRID_STRIDE(i, n)
+  {
+    unsigned int d = deg[i] < 0x7fffffffu ? deg[i] : 0x7ffffffeu;
+    keys[i]        = 2u * d + (d > 0 ? 1u : is_minor[i]);
+  }
+}
+}  // namespace
+
+// Order of a degree-sorted graph: descending major degree, ties by ascending id -- except among
+// the vertices WITHOUT major edges, where those that still occur as a minor come first.  What is
+// left at the very end are the vertices no edge touches; PageRank never has to visit them
+// (pagerank.hip: dead rows).
+void degree_order_sources_first(hipStream_t stream, unsigned int const* deg, int32_t const* minors,
+                                int64_t n_edges, int64_t n, DevBuf& order, DevBuf& rank)
+{
+  size_t nn = static_cast<size_t>(n > 0 ? n : 1);
+  DevBuf is_minor(nn * 4), keys(nn * 4);
+  CGA_HIP(hipMemsetAsync(is_minor.p, 0, is_minor.bytes, stream));
+  if (n_edges > 0)
+    hipLaunchKernelGGL(mark_ids_kernel, dim3(grid_for(n_edges)), dim3(kThreads), 0, stream, minors, n_edges,
+                       is_minor.as<unsigned int>());
+  if (n > 0)
+    hipLaunchKernelGGL(degree_keys_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, deg,
+                       is_minor.as<unsigned int>(), n, keys.as<unsigned int>());
+  degree_order(stream, keys.as<unsigned int>(), n, order, rank);
+}
+
 // order[new] = old, rank[old] = new; stable, descending degree
 void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf& order, DevBuf& rank)
 {
@@ -298,7 +336,7 @@ Graph* degree_sorted_copy(Handle const& h, Graph const& g)
                          stream, static_cast<int32_t const*>(g.offsets), n, deg.as<unsigned int>());
   }
   DevBuf order, rank;
-  degree_order(stream, deg.as<unsigned int>(), n, order, rank);
+  degree_order_sources_first(stream, deg.as<unsigned int>(), g.indices, ne, n, order, rank);
   deg.release();
   DevBuf majors(static_cast<size_t>(ne > 0 ? ne : 1) * 4), minors(static_cast<size_t>(ne > 0 ? ne : 1) * 4);
   expand_offsets(stream, g.offsets, g.off64, n, ne, majors.as<int32_t>());
@@ -418,7 +456,7 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
     hipLaunchKernelGGL(hist_u32_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream,
                        majors_are_dst ? dst32 : src32, ne, deg.as<unsigned int>());
   DevBuf order, rank;
-  degree_order(stream, deg.as<unsigned int>(), nv, order, rank);
+  degree_order_sources_first(stream, deg.as<unsigned int>(), majors_are_dst ? src32 : dst32, ne, nv, order, rank);
   relabel_ids(stream, src32, ne, rank.as<int32_t>());
   relabel_ids(stream, dst32, ne, rank.as<int32_t>());
   // ---- number_map (new -> external) and the external -> new lookup

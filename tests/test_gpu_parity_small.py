@@ -211,6 +211,44 @@ def test_xs_work_items_cut_into_pieces(tile_edges, piece, scale, dtype, weighted
     assert np.max(np.abs(got[top] - o_pr[top]) / o_pr[top]) <= (2e-5 if dtype == np.float32 else 1e-9)
 
 
+@pytest.mark.parametrize("dead_rows", ["0", "1"])
+@pytest.mark.parametrize("dtype,weighted", [(np.float32, False), (np.float64, True)])
+def test_dead_rows_are_skipped_correctly(dead_rows, dtype, weighted, monkeypatch):
+    """Vertices no edge touches (a third of this graph) are visited by the first iteration only;
+    their share of the dangling mass and of the L1 delta is added analytically and their ranks are
+    filled in at the end.  With a non-uniform initial guess on exactly those vertices, the ranks,
+    the iteration count and the convergence flag must equal the oracle's, with the skip on and off."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0")
+    monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1")
+    monkeypatch.setenv("CUGRAPH_AMD_DEAD_ROWS", dead_rows)
+    scale = 14
+    nv, ne = (1 << scale) + 5000, 16 << scale  # 5000 extra ids only the vertex list mentions
+    src, dst = oracle.rmat_edges(scale, ne, seed=11)
+    wgt = oracle.rmat_weights(ne, seed=12).astype(dtype) if weighted else None
+    g, h = make_sg_graph(src, dst, wgt, vertices=np.arange(nv, dtype=np.int32), multigraph=True, renumber=True)
+    rng = np.random.default_rng(3)
+    guess = rng.random(nv).astype(dtype)
+    guess /= guess.sum()
+    eps = 1e-7 if dtype == np.float32 else 1e-12
+    o_off, o_idx, perm = oracle.compress(nv, dst, src)
+    for max_it in (1, 2, 500):
+        v, r, conv = plc.pagerank(h, g, None, None, to_dev(np.arange(nv, dtype=np.int32)), to_dev(guess),
+                                  0.85, eps, max_it, False, fail_on_nonconvergence=False)
+        o_pr, o_it, o_conv = oracle.pagerank(nv, o_off, o_idx, None if wgt is None else wgt[perm],
+                                             dtype=np.float64, alpha=0.85, epsilon=eps,
+                                             max_iterations=max_it, nstart=guess.astype(np.float64))
+        got = np.empty(nv, dtype=np.float64)
+        got[v.cpu().numpy()] = r.cpu().numpy().astype(np.float64)
+        assert bool(conv) == o_conv
+        assert np.max(np.abs(got - o_pr)) <= (1e-6 if dtype == np.float32 else 1e-10)
+        dead = (np.bincount(dst, minlength=nv) == 0) & (np.bincount(src, minlength=nv) == 0)
+        assert dead.sum() >= 5000
+        assert np.max(np.abs(got[dead] - o_pr[dead]) / o_pr[dead]) <= (1e-5 if dtype == np.float32 else 1e-9)
+
+
 @pytest.mark.parametrize("name", ["karate.csv", "dolphins.csv", "netscience.csv"])
 @pytest.mark.parametrize("id_dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("transposed", [True, False])
@@ -232,9 +270,16 @@ def test_renumber_true_external_ids(name, id_dtype, transposed):
     assert nmap.dtype == id_dtype and sorted(nmap.tolist()) == sorted(ext.tolist())
     deg = np.diff(off)
     assert np.all(deg[:-1] >= deg[1:])  # descending major degree
-    # ties by ascending external id (stable)
-    same = deg[:-1] == deg[1:]
+    # ties by ascending external id (stable); among the vertices without major edges those that
+    # still occur as a minor come first (the ones no edge touches end up last)
+    touched = np.zeros(nv, bool)
+    touched[(dst if transposed else src)] = True  # rows are dst when transposed: minors are src ...
+    is_minor = np.zeros(nv, bool)
+    is_minor[(src if transposed else dst)] = True
+    key2 = np.where(deg > 0, 1, is_minor[[int((e + 50) // 7) for e in nmap]].astype(int))
+    same = (deg[:-1] == deg[1:]) & (key2[:-1] == key2[1:])
     assert np.all(nmap[:-1][same] < nmap[1:][same])
+    assert np.all(key2[:-1][deg[:-1] == deg[1:]] >= key2[1:][deg[:-1] == deg[1:]])
     # stored structure == oracle CSC of the relabelled edge list
     inv = {int(e): i for i, e in enumerate(nmap)}
     s2 = np.array([inv[int(e)] for e in ext[src]], np.int32)

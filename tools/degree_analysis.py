@@ -24,3 +24,8 @@ od = outdeg[order]
 oc = torch.cumsum(od, 0)
 for thr in (1 << 13, 1 << 15, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24):
     print(f"out-edges of the top {thr} rows by in-degree: {int(oc[thr-1])/ne:.4f}")
+iso = indeg == 0
+print("rows without in-edges:", int(iso.sum()), " of those with out-edges:", int((iso & (outdeg > 0)).sum()),
+      " with neither (dead):", int((iso & (outdeg == 0)).sum()))
+low = (indeg >= 1) & (indeg <= 3)
+print("rows of in-degree 1-3:", int(low.sum()), " of those with out-edges:", int((low & (outdeg > 0)).sum()))
