@@ -2017,8 +2017,11 @@ void session_setup(Session& s, PagerankArgs const& a)
   }
 
   int n_prep_blocks = session_geometry<ValT>(s, plan);
-  // a personalized run gives a dead row its own rank (teleport * p_v): then they are all visited
-  s.n_dead = (!s.personalized && plan.contiguous && plan.n_dead <= s.buckets[4].count) ? plan.n_dead : 0;
+  // a personalized run gives a dead row its own rank (teleport * p_v), and out-weight sums given
+  // by the caller may call a dead row non-dangling: then they are all visited
+  s.n_dead = (!s.personalized && !a.pre_sums && plan.contiguous && plan.n_dead <= s.buckets[4].count)
+               ? plan.n_dead
+               : 0;
 
   // ---- x0 and the dangling mass of pr0
   hipLaunchKernelGGL((prep_kernel<ValT>), dim3(n_prep_blocks), dim3(kThreads), 0, stream,
