@@ -1,0 +1,65 @@
+"""Local compute of ONE rank of a P-way 1D partition, on one GPU and without collectives: the same
+local graph (per-rank degree order, compact source slots of all ranks) the multi-GPU driver builds,
+then timed iterations.  usage: rank_emulate.py <scale> <P> [rank]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cugraph_amd import generators, mg, pylibcugraph as plc
+
+scale, world = int(sys.argv[1]), int(sys.argv[2])
+me = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+nv, ne = 1 << scale, 16 << scale
+h = plc.ResourceHandle(rank=me, comm_size=world)
+props = plc.GraphProperties(is_multigraph=True)
+src, dst = generators.rmat(h, scale, ne, seed=42, scramble_vertex_ids=True)
+indeg = torch.zeros(nv, dtype=torch.int32, device="cuda")
+outdeg = torch.zeros(nv, dtype=torch.int32, device="cuda")
+one = torch.ones(1 << 28, dtype=torch.int32, device="cuda")
+for b in range(0, ne, 1 << 28):  # in pieces: index_add_ wants int64 indices
+    e = min(b + (1 << 28), ne)
+    indeg.index_add_(0, dst[b:e].long(), one[:e - b])
+    outdeg.index_add_(0, src[b:e].long(), one[:e - b])
+del one
+chunk = (nv + world - 1) // world
+slot_of = torch.full((nv,), -1, dtype=torch.int32, device="cuda")
+orders, actives = [], []
+for r in range(world):
+    first, last, _ = mg.partition_bounds(nv, world, r)
+    order = torch.sort(indeg[first:last], descending=True, stable=True).indices
+    orders.append(order)
+    actives.append(outdeg[first:last][order] > 0)
+slot_chunk = max(int(a.sum()) for a in actives)
+slot_chunk = (slot_chunk + 3) // 4 * 4
+for r in range(world):
+    first, last, _ = mg.partition_bounds(nv, world, r)
+    a = actives[r]
+    x_pos = torch.where(a, torch.cumsum(a, 0) - 1 + r * slot_chunk, torch.full_like(orders[r], -1)).to(torch.int32)
+    slot_of[first + orders[r]] = x_pos
+    if r == me:
+        my_x_pos = x_pos
+first, last, _ = mg.partition_bounds(nv, world, me)
+parts_s, parts_d = [], []
+for b in range(0, ne, 1 << 28):  # in pieces: one mask over 4 G edges is more than torch indexes
+    e = min(b + (1 << 28), ne)
+    sel = (dst[b:e] >= first) & (dst[b:e] < last)
+    parts_s.append(src[b:e][sel])
+    parts_d.append(dst[b:e][sel])
+s_l, d_l = torch.cat(parts_s), torch.cat(parts_d)
+del src, dst, sel, parts_s, parts_d
+rank_l = torch.empty_like(orders[me], dtype=torch.int32)
+rank_l[orders[me]] = torch.arange(last - first, dtype=torch.int32, device="cuda")
+eng = mg.HipEngine(h, props)
+g = eng.make_local_graph(slot_of[s_l.long()], rank_l[(d_l - first).long()] + first, None, first, last, nv,
+                         num_source_slots=slot_chunk * world, x_pos=my_x_pos)
+n_local_edges = int(s_l.numel())
+del s_l, d_l
+ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
+sums = outdeg[first:last][orders[me]].to(torch.float32)
+sess = eng.make_session(g, alpha=0.85, epsilon=0.0, precomputed_vertex_out_weight_vertices=ids,
+                        precomputed_vertex_out_weight_sums=sums)
+sess.iterate(3)
+torch.cuda.synchronize()
+it, km = sess.timed_iterate(10)
+print(f"scale {scale}, rank {me} of {world}: {last - first} rows, {n_local_edges} edges, {slot_chunk * world} source slots; "
+      f"local iteration {it.mean():.3f} ms (dominant kernel {km.mean():.3f} ms) -> {ne / it.mean() / 1e6:.0f} GTEPS if every "
+      f"rank took this long and the exchange were free; gathered vector {slot_chunk * world * 4 / 1e6:.0f} MB")
