@@ -109,6 +109,9 @@ SIGNATURES = {
     "cugraph_amd_pagerank_session_create": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl,
                                                    _int, _vpp, _vpp]),
     "cugraph_amd_pagerank_session_iterate": (_int, [_vp, _sz, _vpp]),
+    "cugraph_amd_pagerank_session_iterate_phase": (_int, [_vp, _int, _vpp]),
+    "cugraph_amd_graph_set_hot_slots": (_int, [_vp, ctypes.c_int64, _vpp]),
+    "cugraph_amd_xs_window_slots": (ctypes.c_int64, [ctypes.c_int64]),
     "cugraph_amd_pagerank_session_timed_iterate": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_float),
                                                           ctypes.POINTER(ctypes.c_float), _vpp]),
     "cugraph_amd_pagerank_session_exchange_buffers": (_int, [_vp, _vpp, _vpp, _vpp]),

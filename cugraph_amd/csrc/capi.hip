@@ -12,6 +12,8 @@ namespace cga {
 struct Session;
 Session* session_create(Handle const& h, Graph& g, PagerankArgs const& a);
 void session_iterate(Session& s, size_t n);
+void session_iterate_phase(Session& s, int phase);
+int64_t xs_window_slots(int64_t num_source_slots);
 void session_timed_iterate(Session& s, size_t n, float* iter_ms, float* kernel_ms);
 void session_status(Session& s, size_t* iters, bool* stopped, double* delta, double* dangling);
 CentralityResult* session_result(Session& s, size_t max_iterations);
@@ -979,6 +981,31 @@ cugraph_error_code_t cugraph_amd_pagerank_session_iterate(cugraph_amd_pagerank_s
     session_iterate(*as<Session>(session), n);
   });
 }
+
+cugraph_error_code_t cugraph_amd_pagerank_session_iterate_phase(cugraph_amd_pagerank_session_t* session,
+                                                                int phase, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(session, CUGRAPH_INVALID_INPUT, "session is NULL");
+    session_iterate_phase(*as<Session>(session), phase);
+  });
+}
+
+cugraph_error_code_t cugraph_amd_graph_set_hot_slots(cugraph_graph_t* graph, int64_t hot_slots,
+                                                     cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(graph, CUGRAPH_INVALID_INPUT, "graph is NULL");
+    Graph* g = as<Graph>(graph);
+    CGA_EXPECTS(g->x_pos != nullptr && hot_slots >= 0 && hot_slots <= g->num_source_slots, CUGRAPH_INVALID_INPUT,
+                "hot_slots: needs a graph with a compact source space and 0 <= hot_slots <= num_source_slots");
+    CGA_EXPECTS(g->plan == nullptr, CUGRAPH_INVALID_INPUT,
+                "hot_slots must be set before the first PageRank call on the graph");
+    g->hot_slots = hot_slots;
+  });
+}
+
+int64_t cugraph_amd_xs_window_slots(int64_t num_source_slots) { return xs_window_slots(num_source_slots); }
 
 cugraph_error_code_t cugraph_amd_pagerank_session_timed_iterate(
   cugraph_amd_pagerank_session_t* session, size_t n, float* iteration_ms, float* spmv_kernel_ms,

@@ -160,6 +160,9 @@ struct Graph {
   // and x_pos[row] is the slot row's own value goes to (-1: no edge leaves it, nobody gathers it)
   int64_t num_source_slots{0};     // 0: minors are vertex ids in [0, num_global_vertices)
   int32_t* x_pos{nullptr};
+  // slots below hot_slots are the first REGION of the gathered vector (all-gathered first, see
+  // cugraph_amd_graph_set_hot_slots); 0: one region
+  int64_t hot_slots{0};
   int64_t num_edges{0};
   bool off64{false};
 

@@ -581,15 +581,17 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
       uint32_t wb[kXsRegWindows];
 #pragma unroll
       for (int w = 1; w < kXsRegWindows; ++w) {
-        int64_t d = uniform64(rec[4 + w]) - abeg;  // INT64_MAX for windows the graph does not have
-        wb[w]     = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : static_cast<uint32_t>(d);
+        // INT64_MAX for windows the graph does not have; a window that starts before this item's
+        // entries (an item can be the tail of a unit: the second region of a partitioned graph)
+        int64_t d = uniform64(rec[4 + w]) - abeg;
+        wb[w]     = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : d < 0 ? 0u : static_cast<uint32_t>(d);
       }
       auto window_of = [&](uint32_t pos) {
         uint32_t c = 0;
 #pragma unroll
         for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
         for (int w = kXsRegWindows; w < xs.n_win; ++w)  // very large source spaces only
-          c += pos >= static_cast<uint32_t>(xs.unit_off[u0 + w] - abeg) ? 1u : 0u;
+          c += static_cast<int64_t>(pos) >= xs.unit_off[u0 + w] - abeg ? 1u : 0u;
         return c;
       };
       uint32_t const low_mask = (1u << shift) - 1u;
@@ -809,40 +811,36 @@ __global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT
   write_partials(ep.dangling, ep.delta, partials);
 }
 
-// edges of every tile (for the host, which cuts big tiles into pieces)
-template <typename OffT>
-__global__ void xs_tile_edges_kernel(OffT const* __restrict__ offsets, int64_t row_first,
-                                     int32_t const* __restrict__ tile_row, int n_tiles,
-                                     int64_t* __restrict__ out)
-{
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += gridDim.x * blockDim.x)
-    out[t] = static_cast<int64_t>(offsets[row_first + tile_row[t + 1]]) -
-             static_cast<int64_t>(offsets[row_first + tile_row[t]]);
-}
-
 // One record per (slice, work item): what xs_kernel needs to start on that piece of the unit.
 //  [0] tile | piece << 32 | pieces << 40   [1] first row | rows << 32   [2] offset of its partials
-//  [3] first entry  [4] end of the unit's entries  [5..19] start of windows 1..15 (INT64_MAX: none)
-__global__ void xs_records_kernel(uint32_t const* __restrict__ items, int n_items,
+//  [3] first entry  [4] end of the item's entries  [5..19] start of windows 1..15 (INT64_MAX: none)
+// An item covers the windows [win_lo, win_hi) of its unit (all of them, or one region of a
+// partitioned graph's source space) and is piece `piece` of `pieces` of that range; its partials
+// are set k * tile_sets[tile] + item.pset of the tile's sets.
+struct XsItem {
+  int32_t tile, piece, pieces, pset;
+};
+__global__ void xs_records_kernel(XsItem const* __restrict__ items, int n_items,
                                   int32_t const* __restrict__ tile_row,
                                   int64_t const* __restrict__ unit_off,
-                                  int64_t const* __restrict__ pbase, int n_win,
+                                  int64_t const* __restrict__ pbase, int n_win, int win_lo, int win_hi,
                                   int64_t* __restrict__ rec)
 {
   int64_t total = static_cast<int64_t>(kXsSlices) * n_items;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     int k = static_cast<int>(i / n_items), q = static_cast<int>(i % n_items);
-    uint32_t it = items[q];
-    int64_t t = it >> 8, piece = (it >> 4) & 15, n_pc = it & 15;
+    XsItem it = items[q];
+    int64_t t = it.tile, piece = it.piece, n_pc = it.pieces;
     int64_t row0 = tile_row[t], rows = tile_row[t + 1] - row0;
+    int64_t sets = (pbase[t + 1] - pbase[t]) / (rows * kXsSlices);
     int64_t u0 = (t * kXsSlices + k) * n_win;
     int64_t* r = rec + i * kXsRecWords;
     r[0] = t | (piece << 32) | (n_pc << 40);
     r[1] = row0 | (rows << 32);
-    r[2] = pbase[t] + (k * n_pc + piece) * rows;
-    r[3] = unit_off[u0];
-    r[4] = unit_off[u0 + n_win];
+    r[2] = pbase[t] + (k * sets + it.pset) * rows;
+    r[3] = unit_off[u0 + win_lo];
+    r[4] = unit_off[u0 + win_hi];
     for (int w = 1; w < kXsRegWindows; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
     for (int w = 4 + kXsRegWindows; w < kXsRecWords; ++w) r[w] = 0;
   }
@@ -1280,10 +1278,12 @@ struct PullPlan {
   // XS tiles over the rows of buckets 1 and 2 (only on a degree-sorted compute graph)
   bool xs_on{false};
   int64_t xs_row_first{0}, xs_n_rows{0}, xs_n_edges{0};
-  int xs_n_tiles{0}, xs_n_items{0}, xs_n_fin_items{0};
+  int xs_n_tiles{0}, xs_n_fin_items{0};
+  int xs_regions{1};        // 2: region 0 (hot slots) and region 1 have item lists of their own
+  int xs_n_items[2]{0, 0};  // work items per slice queue, per region
   int64_t xs_partial_len{0};
   int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
-  DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec, xs_pbase, xs_fin_items;
+  DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec[2], xs_pbase, xs_fin_items;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
   int64_t n_hub_items{0};
@@ -1362,6 +1362,16 @@ void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipStreamSynchronize(stream));
 }
 
+// rows per tile (as a power of two) for a source space of `minor_space` ids or slots: see build_xs
+int xs_row_bits_for(int64_t minor_space, int slice_shift)
+{
+  uint32_t const last_local = xs_slice_local(static_cast<uint32_t>(minor_space - 1), slice_shift) |
+                              ((1u << slice_shift) - 1u);
+  int row_bits = kXsRowBitsMax;
+  while (row_bits > kXsRowBits && (last_local >> (32 - row_bits)) >= static_cast<uint32_t>(kXsRegWindows)) --row_bits;
+  return row_bits;
+}
+
 template <typename OffT, typename ValT>
 void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
 {
@@ -1396,10 +1406,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // (xs_kernel, 12 / 13 / 14 bits): scale 22 0.190 / 0.146 / 0.129 ms, scale 24 0.503 / 0.457 /
   // 0.438, scale 26 with compact slots (multi-GPU layout) 2.14 / 1.96 / 1.86.
   char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
-  uint32_t const last_local = xs_slice_local(static_cast<uint32_t>(g.minor_space() - 1), slice_shift) |
-                              ((1u << slice_shift) - 1u);
-  int row_bits = kXsRowBitsMax;
-  while (row_bits > kXsRowBits && (last_local >> (32 - row_bits)) >= static_cast<uint32_t>(kXsRegWindows)) --row_bits;
+  int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
   if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
@@ -1475,52 +1482,77 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int64_t piece_entries      = row_bits == kXsRowBits ? kXsPieceEntries : 64 * pass_entries;
   while (piece_entries > 16 * pass_entries && piece_entries * 1024 > ne) piece_entries >>= 1;
   if (pc_env) piece_entries = std::atoll(pc_env);
-  DevBuf tile_ne(static_cast<size_t>(n_tiles) * 8);
-  hipLaunchKernelGGL((xs_tile_edges_kernel<OffT>), dim3(grid_for(n_tiles)), dim3(kThreads), 0, stream,
-                     offsets, row_first, plan.xs_tile_row.as<int32_t>(), n_tiles, tile_ne.as<int64_t>());
-  std::vector<int64_t> h_ne(n_tiles);
+  // Regions (partitioned graphs, Graph::hot_slots): the source slots below hot_slots -- whole
+  // windows -- are region 0, the rest region 1.  Entries are sorted by slot, so region 0 of a unit
+  // is a prefix of it that ends on a window boundary: two item lists and record tables over the
+  // same entry stream, so that xs_kernel can run on region 0 while region 1 is still being
+  // all-gathered.  Without regions everything is region 0.
+  int w0 = 0;
+  {
+    int64_t const win_slots = static_cast<int64_t>(kXsSlices) << (32 - row_bits);
+    if (g.hot_slots > 0 && g.hot_slots % win_slots == 0 && g.hot_slots / win_slots < n_win)
+      w0 = static_cast<int>(g.hot_slots / win_slots);
+  }
+  std::vector<int64_t> h_uoff(static_cast<size_t>(n_units + 1));
   std::vector<int32_t> h_row(n_tiles + 1);
-  CGA_HIP(hipMemcpyAsync(h_ne.data(), tile_ne.p, static_cast<size_t>(n_tiles) * 8, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipMemcpyAsync(h_uoff.data(), plan.xs_unit_off.p, h_uoff.size() * 8, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipMemcpyAsync(h_row.data(), plan.xs_tile_row.p, static_cast<size_t>(n_tiles + 1) * 4,
                          hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
-  std::vector<uint32_t> h_items;
+  std::vector<XsItem> h_items[2];
   std::vector<int64_t> h_fin;
   std::vector<int64_t> h_pbase(n_tiles + 1);
   int64_t plen = 0;
   for (int t = 0; t < n_tiles; ++t) {
-    int64_t per_unit = h_ne[t] / kXsSlices;
-    int64_t n_pc     = std::min<int64_t>(15, std::max<int64_t>(1, (per_unit + piece_entries / 2) / piece_entries));
-    for (int64_t j = 0; j < n_pc; ++j)
-      h_items.push_back(static_cast<uint32_t>(t) << 8 | static_cast<uint32_t>(j) << 4 | static_cast<uint32_t>(n_pc));
-    h_pbase[t] = plen;
-    plen += static_cast<int64_t>(kXsSlices) * n_pc * (h_row[t + 1] - h_row[t]);
+    // entries of the tile in each region, per unit on average
+    int64_t cnt[2] = {0, 0};
+    for (int k = 0; k < kXsSlices; ++k) {
+      int64_t u0 = (static_cast<int64_t>(t) * kXsSlices + k) * n_win;
+      int64_t mid = w0 > 0 ? h_uoff[u0 + w0] : h_uoff[u0 + n_win];
+      cnt[0] += mid - h_uoff[u0];
+      cnt[1] += h_uoff[u0 + n_win] - mid;
+    }
+    int32_t sets = 0;
+    for (int reg = 0; reg < (w0 > 0 ? 2 : 1); ++reg) {
+      int64_t per_unit = cnt[reg] / kXsSlices;
+      int32_t n_pc = static_cast<int32_t>(
+        std::min<int64_t>(15, std::max<int64_t>(1, (per_unit + piece_entries / 2) / piece_entries)));
+      for (int32_t j = 0; j < n_pc; ++j) h_items[reg].push_back(XsItem{t, j, n_pc, sets + j});
+      sets += n_pc;
+    }
     int64_t const rows_t = h_row[t + 1] - h_row[t];
+    h_pbase[t] = plen;
+    plen += static_cast<int64_t>(kXsSlices) * sets * rows_t;
     for (int64_t r = 0; r < rows_t; r += kXsFinishRows) {
       h_fin.push_back(h_row[t] + r);
-      h_fin.push_back(std::min<int64_t>(kXsFinishRows, rows_t - r) | (kXsSlices * n_pc) << 32);
+      h_fin.push_back(std::min<int64_t>(kXsFinishRows, rows_t - r) | static_cast<int64_t>(kXsSlices * sets) << 32);
       h_fin.push_back(h_pbase[t] + r);
       h_fin.push_back(rows_t);
     }
   }
   h_pbase[n_tiles] = plen;
-  if (n_tiles >= (1 << 24) || h_items.size() >= 0x7fffffffu / kXsSlices) return;
-  int n_items = static_cast<int>(h_items.size());
-  DevBuf items(static_cast<size_t>(n_items) * 4);
+  if (n_tiles >= (1 << 24) || h_items[0].size() + h_items[1].size() >= 0x7fffffffu / kXsSlices) return;
   plan.xs_pbase.alloc(static_cast<size_t>(n_tiles + 1) * 8);
-  plan.xs_rec.alloc(static_cast<size_t>(kXsSlices) * n_items * kXsRecWords * 8);
-  CGA_HIP(hipMemcpyAsync(items.p, h_items.data(), items.bytes, hipMemcpyHostToDevice, stream));
   CGA_HIP(hipMemcpyAsync(plan.xs_pbase.p, h_pbase.data(), plan.xs_pbase.bytes, hipMemcpyHostToDevice, stream));
-  hipLaunchKernelGGL(xs_records_kernel, dim3(grid_for(static_cast<int64_t>(kXsSlices) * n_items)),
-                     dim3(kThreads), 0, stream, items.as<uint32_t>(), n_items,
-                     plan.xs_tile_row.as<int32_t>(), plan.xs_unit_off.as<int64_t>(),
-                     plan.xs_pbase.as<int64_t>(), n_win, plan.xs_rec.as<int64_t>());
-  CGA_HIP(hipGetLastError());
-  CGA_HIP(hipStreamSynchronize(stream));
+  for (int reg = 0; reg < 2; ++reg) {
+    int n_items = static_cast<int>(h_items[reg].size());
+    plan.xs_n_items[reg] = n_items;
+    if (n_items == 0) continue;
+    DevBuf items(static_cast<size_t>(n_items) * sizeof(XsItem));
+    plan.xs_rec[reg].alloc(static_cast<size_t>(kXsSlices) * n_items * kXsRecWords * 8);
+    CGA_HIP(hipMemcpyAsync(items.p, h_items[reg].data(), items.bytes, hipMemcpyHostToDevice, stream));
+    int const lo = reg == 0 ? 0 : w0, hi = (reg == 0 && w0 > 0) ? w0 : n_win;
+    hipLaunchKernelGGL(xs_records_kernel, dim3(grid_for(static_cast<int64_t>(kXsSlices) * n_items)),
+                       dim3(kThreads), 0, stream, items.as<XsItem>(), n_items,
+                       plan.xs_tile_row.as<int32_t>(), plan.xs_unit_off.as<int64_t>(),
+                       plan.xs_pbase.as<int64_t>(), n_win, lo, hi, plan.xs_rec[reg].as<int64_t>());
+    CGA_HIP(hipGetLastError());
+    CGA_HIP(hipStreamSynchronize(stream));
+  }
   plan.xs_fin_items.alloc(h_fin.size() * 8);
   CGA_HIP(hipMemcpy(plan.xs_fin_items.p, h_fin.data(), h_fin.size() * 8, hipMemcpyHostToDevice));
   plan.xs_n_fin_items = static_cast<int>(h_fin.size() / 4);
-  plan.xs_n_items     = n_items;
+  plan.xs_regions     = w0 > 0 ? 2 : 1;
   plan.xs_partial_len = plen;
   plan.xs_on        = true;
   plan.xs_row_first = row_first;
@@ -1835,7 +1867,8 @@ int session_geometry(Session& s, PullPlan& plan)
     char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
     // as many workgroups as are resident at once (LDS-bound): 4 of 256 threads, 2 of 512 or 1 of 1024 per CU
     int want       = xb ? std::atoi(xb) : 1024 >> (plan.xs_row_bits - kXsRowBits);
-    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.xs_n_items) * kXsSlices, want));
+    s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(
+      static_cast<int64_t>(std::max(plan.xs_n_items[0], plan.xs_n_items[1])) * kXsSlices, want));
   }
   if (s.xs_on) {
     s.xs_partial.alloc(static_cast<size_t>(plan.xs_partial_len) * vb);
@@ -2034,11 +2067,19 @@ void session_setup(Session& s, PagerankArgs const& a)
 }
 
 template <typename OffT, typename ValT>
+// phase: -1 the whole iteration; on a graph with two regions of source slots (xs_regions == 2)
+// 0 = what needs region 0 only (xs_kernel over its items), 1 = the rest of the iteration.  On a
+// graph without regions phase 0 is empty and phase 1 the whole iteration.
 void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end,
-                       ValT const* raw_x = nullptr, ValT* raw_y = nullptr)
+                       ValT const* raw_x = nullptr, ValT* raw_y = nullptr, int phase = -1)
 {
   Graph const& g     = *s.cg;
   hipStream_t stream = s.handle->stream;
+  bool const split   = s.xs_on && s.graph->plan->xs_regions == 2;
+  if (!split) {
+    if (phase == 0) return;
+    phase = -1;
+  }
   int cur = static_cast<int>(s.enqueued & 1), nxt = cur ^ 1;
   IterArgs<OffT, ValT> a{};
   a.offsets         = static_cast<OffT const*>(g.offsets);
@@ -2084,15 +2125,15 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.w         = plan.xs_w.p ? plan.xs_w.as<ValT>() : nullptr;
     a.xs.unit_off  = plan.xs_unit_off.as<int64_t>();
     a.xs.tile_row  = plan.xs_tile_row.as<int32_t>();
-    a.xs.rec       = plan.xs_rec.as<int64_t>();
+    a.xs.rec       = plan.xs_rec[0].as<int64_t>();
     a.xs.pbase     = plan.xs_pbase.as<int64_t>();
-    a.xs.n_items   = plan.xs_n_items;
+    a.xs.n_items   = plan.xs_n_items[0];
     a.xs.partial   = s.xs_partial.as<ValT>();
     a.xs.counters  = s.xs_counters.as<int>();
     a.xs.row_first = plan.xs_row_first;
     a.xs.n_rows    = plan.xs_n_rows;
     a.xs.n_tiles   = plan.xs_n_tiles;
-    CGA_HIP(hipMemsetAsync(s.xs_counters.p, 0, 256, stream));
+    if (phase != 1) CGA_HIP(hipMemsetAsync(s.xs_counters.p, 0, 256, stream));  // both regions' queues
   }
   for (int b = 0; b < kNumBuckets; ++b) a.buckets[b] = s.buckets[b];
   // dead rows (the tail of the isolated bucket): visited by the first iteration only, whose old
@@ -2111,7 +2152,14 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   }
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
-  if (s.xs_on && s.n_xs_blocks > 0) {
+  for (int region = 0; region < (split ? 2 : 1); ++region) {
+    if (!(s.xs_on && s.n_xs_blocks > 0)) break;
+    if ((region == 0 && phase == 1) || (region == 1 && phase == 0)) continue;
+    PullPlan const& plan = *s.graph->plan;
+    if (plan.xs_n_items[region] == 0) continue;
+    a.xs.rec      = plan.xs_rec[region].as<int64_t>();
+    a.xs.n_items  = plan.xs_n_items[region];
+    a.xs.counters = s.xs_counters.as<int>() + kXsSlices * region;
     static bool const profile = std::getenv("CUGRAPH_AMD_XS_PROFILE") != nullptr;
     auto launch_xs = [&](auto weighted_tag, auto profile_tag) {
       constexpr bool W  = decltype(weighted_tag)::value;
@@ -2143,6 +2191,10 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     } else {
       launch_xs(std::false_type{}, std::false_type{});
     }
+  }
+  if (phase == 0) {
+    CGA_HIP(hipGetLastError());
+    return;
   }
   // the dominant kernel: xs_kernel when the graph has XS tiles, else spmv_kernel
   if (ev_kernel_end && s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
@@ -2180,15 +2232,15 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   s.enqueued += 1;
 }
 
-void enqueue_dispatch(Session& s, hipEvent_t b, hipEvent_t e)
+void enqueue_dispatch(Session& s, hipEvent_t b, hipEvent_t e, int phase = -1)
 {
   bool o64 = s.cg->off64;
   if (s.f64) {
-    if (o64) enqueue_iteration<int64_t, double>(s, b, e);
-    else enqueue_iteration<int32_t, double>(s, b, e);
+    if (o64) enqueue_iteration<int64_t, double>(s, b, e, nullptr, nullptr, phase);
+    else enqueue_iteration<int32_t, double>(s, b, e, nullptr, nullptr, phase);
   } else {
-    if (o64) enqueue_iteration<int64_t, float>(s, b, e);
-    else enqueue_iteration<int32_t, float>(s, b, e);
+    if (o64) enqueue_iteration<int64_t, float>(s, b, e, nullptr, nullptr, phase);
+    else enqueue_iteration<int32_t, float>(s, b, e, nullptr, nullptr, phase);
   }
 }
 
@@ -2226,6 +2278,20 @@ void session_iterate(Session& s, size_t n)
 {
   if (s.n_global == 0) return;
   for (size_t i = 0; i < n; ++i) enqueue_dispatch(s, nullptr, nullptr);
+}
+
+// slots of one XS window for a gathered vector of num_source_slots slots: the granule of a region
+int64_t xs_window_slots(int64_t num_source_slots)
+{
+  if (num_source_slots <= 0) return 0;
+  return static_cast<int64_t>(kXsSlices) << (32 - xs_row_bits_for(num_source_slots, 7));
+}
+
+void session_iterate_phase(Session& s, int phase)
+{
+  CGA_EXPECTS(phase == 0 || phase == 1, CUGRAPH_INVALID_INPUT, "phase must be 0 or 1");
+  if (s.n_global == 0) return;
+  enqueue_dispatch(s, nullptr, nullptr, phase);
 }
 
 void session_timed_iterate(Session& s, size_t n, float* iter_ms, float* kernel_ms)

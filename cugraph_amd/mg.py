@@ -68,6 +68,27 @@ def all_gather_in_place(x_full, chunk, rank, world, group=None):
         dist.all_gather(parts, mine.clone(), group=group)
 
 
+class _Done:
+    """Stand-in for the work handle of a collective that already ran (backends without the async flat form)."""
+
+    def wait(self):
+        return True
+
+
+def all_gather_region_async(region, sub_chunk, rank, world, group=None):
+    """In-place all-gather of one region of the gathered vector (P equal sub-chunks, rank r's is
+    the r-th), started without waiting: returns a handle whose wait() orders the current stream
+    behind it."""
+    dist = _dist()
+    mine = region[rank * sub_chunk:(rank + 1) * sub_chunk]
+    try:
+        return dist.all_gather_into_tensor(region, mine, group=group, async_op=True)
+    except (RuntimeError, NotImplementedError):  # gloo: no flat form
+        parts = list(region.split(sub_chunk))
+        dist.all_gather(parts, mine.clone(), group=group)
+        return _Done()
+
+
 def shuffle_edges_to_owner(src, dst, wgt, chunk, world, group=None):
     """Route every edge to the rank that owns its destination (one all-to-all per array)."""
     import torch
@@ -124,12 +145,18 @@ class HipEngine:
         return order, rank
 
     def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
-                         x_pos=None):
+                         x_pos=None, hot_slots=0):
         from . import pylibcugraph as plc
 
         return plc.MGGraph(self.handle, self.props, src, dst, wgt, vertex_first=first,
                            vertex_last=last, num_global_vertices=num_global,
-                           num_source_slots=num_source_slots, x_pos=x_pos)
+                           num_source_slots=num_source_slots, x_pos=x_pos, hot_slots=hot_slots)
+
+    def window_slots(self, num_source_slots):
+        """Granule of a region of the gathered vector (cugraph_amd_xs_window_slots)."""
+        from . import _capi
+
+        return int(_capi.load().cugraph_amd_xs_window_slots(int(num_source_slots)))
 
     def source_weight_sums(self, src, wgt, num_global):
         """float64[num_global]: per-source sum of the weights (edge counts when wgt is None) of
@@ -163,6 +190,7 @@ class HipEngine:
 class MGSession:
     def __init__(self, inner):
         self.inner = inner
+        self.pending = None  # (region 0, region 1) all-gathers of the current vector still in flight
 
 
 class MGPagerank:
@@ -178,6 +206,9 @@ class MGPagerank:
         self.order = None  # int32[n_local]: internal position -> offset of the caller's id in the range
         self.rank_local = None  # int32[n_local]: offset of the caller's id in the range -> internal position
         self.slot_chunk = 0  # slots per rank of the gathered vector (compact source space)
+        # two regions of the gathered vector: (C0, C1) = per-rank sub-chunk of the hot region
+        # [0, P*C0) and of the rest [P*C0, P*C0 + P*C1); None: one region of P chunks
+        self.regions = None
         self.out_w = None  # out-weight sums of the local vertices (float64), internal order
         self.value_dtype = None
         self.vertex_dtype = None
@@ -216,9 +247,17 @@ class MGPagerank:
         if world > 1:
             dist.all_reduce(n_active, op=dist.ReduceOp.MAX, group=group)
         self.slot_chunk = max(int(n_active.item()), 1)
-        x_pos = torch.where(active, torch.cumsum(active, 0) - 1 + rank * self.slot_chunk,
-                            torch.full_like(order, -1)).to(torch.int32)
-        del active
+        self.regions = self._choose_regions(engine, self.slot_chunk, world)
+        j = torch.cumsum(active, 0) - 1  # index of a row among this rank's sources (row order = hottest first)
+        if self.regions is None:
+            slot = j + rank * self.slot_chunk
+            n_slots, hot_slots = self.slot_chunk * world, 0
+        else:
+            c0, c1 = self.regions
+            slot = torch.where(j < c0, j + rank * c0, j - c0 + world * c0 + rank * c1)
+            n_slots, hot_slots = world * (c0 + c1), world * c0
+        x_pos = torch.where(active, slot, torch.full_like(order, -1)).to(torch.int32)
+        del active, j, slot
         # caller's id -> slot, for every rank's range: one all-gather of the per-rank tables
         slot_of = torch.full((self.chunk * world,), -1, dtype=torch.int32, device=src.device)
         slot_of[self.first + order] = x_pos
@@ -228,7 +267,7 @@ class MGPagerank:
         dst = (self.rank_local[(dst - self.first).long()] + self.first).to(self.vertex_dtype)
         del slot_of
         self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last, self.num_vertices,
-                                             num_source_slots=self.slot_chunk * world, x_pos=x_pos)
+                                             num_source_slots=n_slots, x_pos=x_pos, hot_slots=hot_slots)
         del src, dst, wgt, x_pos
         self.out_w = sums[self.first:self.last][order].clone()  # internal (row) order
         del sums, counts
@@ -293,17 +332,80 @@ class MGPagerank:
         self._exchange(sess)  # x0 and the dangling mass of pr0
         return sess
 
+    @staticmethod
+    def _choose_regions(engine, max_sources, world):
+        """(C0, C1) or None.  Region 0 is ONE window of the XS layout (about 2 M slots: the hottest
+        C0 sources of every rank, most of all gathers), region 1 the rest; each region is P equal
+        sub-chunks, so each is one all-gather, and the second can run beside the part of the
+        iteration that needs only the first (MGPagerank.iterate).  Two regions cost a second set
+        of partial sums per row (one rank at scale 26: +0.2 ms per iteration), which pays once the
+        exchange is a sizeable part of the iteration: on by default from 4 ranks.
+        CUGRAPH_AMD_MG_REGIONS=0 / 1: never / whenever the layout allows."""
+        import os
+
+        mode = os.environ.get("CUGRAPH_AMD_MG_REGIONS", "auto")
+        if mode == "0" or (mode != "1" and world < 4) or not hasattr(engine, "window_slots"):
+            return None
+        total = world * max_sources
+        for _ in range(3):  # the window size depends on the number of slots, which the padding changes
+            win = engine.window_slots(total)
+            if win <= 0 or win % world:
+                return None
+            c0 = win // world
+            if max_sources <= c0:
+                return None  # everything fits the first window
+            c1 = (max_sources - c0 + 3) // 4 * 4
+            if world * (c0 + c1) == total:
+                return c0, c1
+            total = world * (c0 + c1)
+        return None
+
+    def _region_views(self, x_full):
+        c0, c1 = self.regions
+        hot = self.world * c0
+        return (x_full[:hot], c0), (x_full[hot:hot + self.world * c1], c1)
+
     def _exchange(self, sess):
+        """All-gather of the source vector and all-reduce of the two scalars, waited for."""
         if self.world == 1 and not self.always_exchange:
             return
+        for w in self._exchange_start(sess):
+            w.wait()
+
+    def _exchange_start(self, sess):
+        """The scalars first (every kernel of the next iteration tests them), then the all-gathers,
+        not waited for: one handle per region."""
         x_full, scal = sess.inner.exchange_buffers()
-        all_gather_in_place(x_full, self.slot_chunk, self.rank, self.world, self.group)
         _dist().all_reduce(scal, group=self.group)
+        if self.regions is None:
+            return (all_gather_region_async(x_full[:self.slot_chunk * self.world], self.slot_chunk, self.rank,
+                                            self.world, self.group),)
+        return tuple(all_gather_region_async(v, c, self.rank, self.world, self.group)
+                     for v, c in self._region_views(x_full))
 
     def iterate(self, sess, n=1):
+        """n iterations.  With two regions, an iteration starts on the hot region as soon as that
+        one has arrived (phase 0: the XS tiles over the hot slots, most of the work) while the
+        all-gather of the other region is still running on the collective's stream; the rest of
+        the iteration (phase 1) waits for it.  Nothing is left in flight when this returns."""
+        if self.world == 1 and not self.always_exchange:
+            sess.inner.iterate(n)
+            return
         for _ in range(n):
-            sess.inner.iterate(1)
-            self._exchange(sess)
+            pend, sess.pending = sess.pending, None
+            if pend and len(pend) == 2:
+                pend[0].wait()
+                sess.inner.iterate_phase(0)
+                pend[1].wait()
+                sess.inner.iterate_phase(1)
+            else:
+                for w in pend or ():
+                    w.wait()
+                sess.inner.iterate(1)
+            sess.pending = self._exchange_start(sess)
+        for w in sess.pending or ():
+            w.wait()
+        sess.pending = None
 
     def timed_iterate(self, sess, n):
         it, km = [], []
@@ -322,9 +424,7 @@ class MGPagerank:
         iters, stopped, delta = 0, False, float("inf")
         while done < budget:
             n = min(check_every, budget - done)
-            for _ in range(n):
-                sess.inner.iterate(1)
-                self._exchange(sess)
+            self.iterate(sess, n)
             done += n
             iters, stopped, delta, _ = sess.inner.status()
             if stopped:

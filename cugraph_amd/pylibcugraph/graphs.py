@@ -111,9 +111,10 @@ class MGGraph(_GPUGraph):
 
     def __init__(self, resource_handle, graph_properties, src_array, dst_array, weight_array=None,
                  *, vertex_first, vertex_last, num_global_vertices, num_source_slots=None,
-                 x_pos=None):
+                 x_pos=None, hot_slots=0):
         """num_source_slots / x_pos: compact source space (src_array then holds slots of the
-        gathered vector, see cugraph_amd_graph_create_local_compact)."""
+        gathered vector, see cugraph_amd_graph_create_local_compact).  hot_slots: the slots below
+        it are the first of two regions of that vector (cugraph_amd_graph_set_hot_slots)."""
         assert_CAI_type(src_array, "src_array")
         assert_CAI_type(dst_array, "dst_array")
         assert_CAI_type(weight_array, "weight_array", True)
@@ -141,3 +142,7 @@ class MGGraph(_GPUGraph):
                 free_view(v)
         self.c_graph_ptr = graph
         self._resource_handle = resource_handle
+        if hot_slots:
+            err = ctypes.c_void_p()
+            code = lib.cugraph_amd_graph_set_hot_slots(graph, int(hot_slots), ctypes.byref(err))
+            _capi.check(code, err, "cugraph_amd_graph_set_hot_slots()")

@@ -42,6 +42,13 @@ class PagerankSession:
         code = self._lib.cugraph_amd_pagerank_session_iterate(self._ptr, int(n), ctypes.byref(err))
         _capi.check(code, err, "cugraph_amd_pagerank_session_iterate")
 
+    def iterate_phase(self, phase):
+        """One iteration in two steps on a graph whose gathered vector has two regions: phase 0
+        needs region 0 only, phase 1 the whole vector (cugraph_amd_pagerank_session_iterate_phase)."""
+        err = ctypes.c_void_p()
+        code = self._lib.cugraph_amd_pagerank_session_iterate_phase(self._ptr, int(phase), ctypes.byref(err))
+        _capi.check(code, err, "cugraph_amd_pagerank_session_iterate_phase")
+
     def timed_iterate(self, n):
         """Returns (iteration_ms[n], spmv_kernel_ms[n]) measured with HIP events; synchronises."""
         it = (ctypes.c_float * n)()

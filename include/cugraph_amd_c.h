@@ -385,6 +385,22 @@ cugraph_error_code_t cugraph_amd_pagerank_session_create(
 cugraph_error_code_t cugraph_amd_pagerank_session_iterate(cugraph_amd_pagerank_session_t* session,
                                                           size_t n, cugraph_error_t** error);
 
+/* Regions of the gathered vector (multi-GPU, no counterpart in the reference).  The driver may
+ * lay the slots out as TWO regions, each the concatenation of P equal per-rank sub-chunks: region
+ * 0 = slots [0, hot_slots), the hottest sources of every rank, region 1 the rest.  Each region is
+ * one all-gather; hot_slots must be a multiple of cugraph_amd_xs_window_slots(num_source_slots)
+ * (otherwise it is ignored: one region).  Set it on a graph made by
+ * cugraph_amd_graph_create_local_compact before the first session on it.  An iteration can then
+ * be enqueued in two steps: phase 0 needs only region 0 (the XS tiles over the hot slots: most of
+ * the work), phase 1 the whole vector (the other slots, the low-degree rows, the rank update,
+ * the scalars) -- so the all-gather of region 1 can run beside phase 0.  iterate() = phase 0
+ * then phase 1.  On a graph without regions phase 0 is empty and phase 1 the whole iteration. */
+int64_t cugraph_amd_xs_window_slots(int64_t num_source_slots);
+cugraph_error_code_t cugraph_amd_graph_set_hot_slots(cugraph_graph_t* graph, int64_t hot_slots,
+                                                     cugraph_error_t** error);
+cugraph_error_code_t cugraph_amd_pagerank_session_iterate_phase(cugraph_amd_pagerank_session_t* session,
+                                                                int phase, cugraph_error_t** error);
+
 /* As iterate(), but brackets every iteration and its SpMV launch with HIP events on the handle's
  * stream, synchronises, and returns the n per-iteration durations and the durations of the
  * dominant kernel (xs_kernel, or spmv_kernel for graphs without XS tiles) in milliseconds

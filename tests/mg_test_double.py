@@ -11,9 +11,10 @@ import torch
 
 
 class _Graph:
-    def __init__(self, src, dst, wgt, first, last, num_global, num_source_slots, x_pos):
+    def __init__(self, src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots=0):
         self.first, self.last, self.num_global = first, last, num_global
         self.slots = num_source_slots
+        self.hot_slots = hot_slots  # slots below it: the first region of the gathered vector
         self.x_pos = x_pos.numpy().astype(np.int64)  # slot of each local row, -1: never gathered
         self.src = src.numpy().astype(np.int64)
         self.dst = dst.numpy().astype(np.int64)
@@ -30,7 +31,15 @@ class _Session:
         assert g.first == min(rank * chunk, g.num_global)
         assert g.slots % world == 0 and np.all(g.src < g.slots)
         mine = g.x_pos[g.x_pos >= 0]
-        assert np.all((mine >= rank * (g.slots // world)) & (mine < (rank + 1) * (g.slots // world)))
+        # this rank writes only its own sub-chunk of each region (one region: P equal chunks)
+        assert g.hot_slots % world == 0 and (g.slots - g.hot_slots) % world == 0
+        c0, c1 = g.hot_slots // world, (g.slots - g.hot_slots) // world
+        hot = mine[mine < g.hot_slots]
+        rest = mine[mine >= g.hot_slots] - g.hot_slots
+        assert np.all((hot >= rank * c0) & (hot < (rank + 1) * c0))
+        assert np.all((rest >= rank * c1) & (rest < (rank + 1) * c1))
+        if g.hot_slots:
+            assert len(hot) == min(c0, len(mine))  # the hot region takes a rank's first (hottest) sources
         self.wr = g.x_pos >= 0
         self.out_w = np.zeros(nl)
         self.out_w[out_w_v.numpy() - g.first] = out_w.numpy()
@@ -77,6 +86,11 @@ class _Session:
             self.pr = pr
             self.iters += 1
 
+    def iterate_phase(self, phase):
+        # the stand-in has no use for the hot region alone: everything happens in phase 1
+        if phase == 1:
+            self.iterate(1)
+
     def exchange_buffers(self):
         return self.x[self.enqueued & 1], self.scal
 
@@ -103,8 +117,12 @@ class OracleEngine:
         return torch.from_numpy(order), torch.from_numpy(rank)
 
     def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
-                         x_pos=None):
-        return _Graph(src, dst, wgt, first, last, num_global, num_source_slots, x_pos)
+                         x_pos=None, hot_slots=0):
+        return _Graph(src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots)
+
+    def window_slots(self, num_source_slots):
+        # small enough for the test graphs to get two regions (the library's are 2^21..2^23 slots)
+        return 48
 
     def source_weight_sums(self, src, wgt, num_global):
         w = np.ones(len(src)) if wgt is None else wgt.numpy().astype(np.float64)

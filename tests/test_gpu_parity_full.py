@@ -172,3 +172,118 @@ def test_config3_scale26_pagerank_properties(monkeypatch):
     a, b = results["xs"][0], results["buckets"][0]
     assert float((a - b).abs().max()) <= 1e-6
     assert np.allclose(results["xs"][1], results["buckets"][1], rtol=1e-5)
+
+
+def test_two_regions_of_the_gathered_vector(monkeypatch):
+    """Multi-GPU layout with TWO regions of the gathered vector (hot slots first) at a scale where
+    the library really cuts its work items at the region boundary (scale 24: four windows of 2 M
+    slots): (a) the driver over RCCL with one rank, phases 0 / 1 and the two all-gathers, against
+    the single-GPU run of the same graph; (b) every rank of a 2-way partition in one process,
+    exchange by hand region by region, against the same."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from cugraph_amd import generators, mg, pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_MG_REGIONS", "1")  # by default only from 4 ranks
+    scale = 24
+    nv, ne = 1 << scale, 16 << scale
+    eps = 1e-6
+    h0, g0, src, dst, _ = _rmat_graph(scale)
+    v, r, conv = plc.pagerank(h0, g0, None, None, None, None, 0.85, eps, 100, False, fail_on_nonconvergence=False)
+    want = r.cpu().numpy().astype(np.float64)
+    assert conv and np.array_equal(v.cpu().numpy(), np.arange(nv))
+    del g0
+    # ---- (a) the driver, one rank, collectives on
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        h = plc.ResourceHandle(rank=0, comm_size=1)
+        drv = mg.MGPagerank.from_edges(mg.HipEngine(h, plc.GraphProperties(is_multigraph=True)), src.clone(),
+                                       dst.clone(), None, nv, rank=0, world=1)
+        assert drv.regions is not None and drv.regions[0] == mg.HipEngine(h, None).window_slots(sum(drv.regions))
+        drv.always_exchange = True
+        sess = drv.session(alpha=0.85, epsilon=eps)
+        iters, stopped, _ = drv.run_to_convergence(sess, 100, check_every=3)
+        full, it2, conv2 = drv.gathered_result(sess, 100)
+        assert stopped and conv2
+        assert np.max(np.abs(full.cpu().numpy().astype(np.float64) - want)) <= 1e-7
+        del sess, drv
+    finally:
+        if own:
+            dist.destroy_process_group()
+    # ---- (b) two ranks emulated in this process
+    world = 2
+    indeg = torch.bincount(dst.long(), minlength=nv)
+    outdeg = torch.bincount(src.long(), minlength=nv)
+    bounds = [mg.partition_bounds(nv, world, r) for r in range(world)]
+    engines = [mg.HipEngine(plc.ResourceHandle(rank=r, comm_size=world), plc.GraphProperties(is_multigraph=True))
+               for r in range(world)]
+    orders, actives = [], []
+    for r in range(world):
+        first, last, _ = bounds[r]
+        order, _ = engines[r].degree_order(dst[(dst >= first) & (dst < last)], first, last)
+        orders.append(order.long())
+        actives.append(outdeg[first:last][orders[r]] > 0)
+    regions = mg.MGPagerank._choose_regions(engines[0], max(int(a.sum()) for a in actives), world)
+    assert regions is not None
+    c0, c1 = regions
+    n_slots, hot = world * (c0 + c1), world * c0
+    slot_of = torch.full((nv,), -1, dtype=torch.int32, device="cuda")
+    x_poss = []
+    for r in range(world):
+        j = torch.cumsum(actives[r], 0) - 1
+        slot = torch.where(j < c0, j + r * c0, j - c0 + hot + r * c1)
+        x_pos = torch.where(actives[r], slot, torch.full_like(slot, -1)).to(torch.int32)
+        slot_of[bounds[r][0] + orders[r]] = x_pos
+        x_poss.append(x_pos)
+    sessions = []
+    graphs = []
+    for r in range(world):
+        first, last, _ = bounds[r]
+        sel = (dst >= first) & (dst < last)
+        rank_l = torch.empty(last - first, dtype=torch.int32, device="cuda")
+        rank_l[orders[r]] = torch.arange(last - first, dtype=torch.int32, device="cuda")
+        g = engines[r].make_local_graph(slot_of[src[sel].long()], rank_l[(dst[sel] - first).long()] + first, None,
+                                        first, last, nv, num_source_slots=n_slots, x_pos=x_poss[r], hot_slots=hot)
+        graphs.append(g)
+        ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
+        sessions.append(engines[r].make_session(
+            g, alpha=0.85, epsilon=eps, precomputed_vertex_out_weight_vertices=ids,
+            precomputed_vertex_out_weight_sums=outdeg[first:last][orders[r]].to(torch.float32)))
+
+    def exchange(region):
+        bufs = [s.exchange_buffers() for s in sessions]
+        lo, c = (0, c0) if region == 0 else (hot, c1)
+        for r in range(world):
+            piece = bufs[r][0][lo + r * c:lo + (r + 1) * c]
+            for q in range(world):
+                if q != r:
+                    bufs[q][0][lo + r * c:lo + (r + 1) * c] = piece
+        if region == 1:
+            scal = sum(b[1] for b in bufs)
+            for b in bufs:
+                b[1].copy_(scal)
+
+    exchange(0), exchange(1)
+    for _ in range(100):
+        # region 0 is complete, region 1 still "in flight": phase 0 must not need it
+        for s in sessions:
+            s.iterate_phase(0)
+        for s in sessions:
+            s.iterate_phase(1)
+        exchange(0), exchange(1)
+        st = [s.status() for s in sessions]
+        assert len({(a[0], a[1]) for a in st}) == 1
+        if st[0][1]:
+            break
+    got = np.zeros(nv)
+    for r, s in enumerate(sessions):
+        first, last, _ = bounds[r]
+        verts, vals, iters_b, conv_b = s.result(100)
+        got[first + orders[r].cpu().numpy()] = vals.cpu().numpy()
+    assert conv_b and iters_b == iters
+    assert np.max(np.abs(got - want)) <= 1e-7

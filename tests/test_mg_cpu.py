@@ -32,6 +32,7 @@ def _worker(rank, world, port, case, out_dir):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CUGRAPH_AMD_MG_REGIONS"] = case.get("regions", "auto")  # two regions of the gathered vector
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         src, dst, wgt, nv = case["src"], case["dst"], case["wgt"], case["nv"]
@@ -42,6 +43,8 @@ def _worker(rank, world, port, case, out_dir):
                                        rank=rank, world=world)
         first, last, chunk = mg.partition_bounds(nv, world, rank)
         assert (drv.first, drv.last) == (first, last)
+        if "want_regions" in case:
+            assert (drv.regions is not None) == case["want_regions"]
         assert drv.graph.first == first and len(drv.out_w) == last - first
         sess = drv.session(alpha=0.85, epsilon=case["eps"], nstart=case.get("nstart"),
                            personalization=case.get("pers"))
@@ -92,10 +95,13 @@ def _rmat_case(scale, weighted, **extra):
     return case
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,regions,want_regions", [(2, "auto", False), (2, "1", True), (3, "1", True),
+                                                        (4, "auto", True), (4, "0", False)])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_mg_matches_single_process_oracle(world, weighted, tmp_path):
-    case = _rmat_case(9, weighted)
+def test_mg_matches_single_process_oracle(world, regions, want_regions, weighted, tmp_path):
+    """regions: the gathered vector as two regions (hot slots first), two all-gathers per iteration and
+    the iteration in two phases -- by default from 4 ranks (the stand-in's window is 48 slots)"""
+    case = _rmat_case(9, weighted, regions=regions, want_regions=want_regions)
     fulls, metas = _run(world, case, tmp_path)
     o_pr, o_it, o_conv = _oracle(case)
     for f, m in zip(fulls, metas):
@@ -110,7 +116,8 @@ def test_mg_personalization_nstart_and_nonconvergence(tmp_path):
     nv = 1 << 9
     pers = (rng.permutation(nv)[:37].astype(np.int64), rng.random(37) + 0.1)  # un-normalised
     nstart = (rng.permutation(nv)[:300].astype(np.int64), rng.random(300))
-    case = _rmat_case(9, True, pers=pers, nstart=nstart, max_iter=4, eps=1e-30, check=1)
+    case = _rmat_case(9, True, pers=pers, nstart=nstart, max_iter=4, eps=1e-30, check=1, regions="1",
+                      want_regions=True)
     fulls, metas = _run(2, case, tmp_path)
     o_pr, o_it, o_conv = _oracle(case)
     assert o_it == 4 and not o_conv
