@@ -30,10 +30,19 @@ for r in range(world):
     actives.append(outdeg[first:last][order] > 0)
 slot_chunk = max(int(a.sum()) for a in actives)
 slot_chunk = (slot_chunk + 3) // 4 * 4
+eng = mg.HipEngine(h, props)
+regions = mg.MGPagerank._choose_regions(eng, slot_chunk, world)  # CUGRAPH_AMD_MG_REGIONS=0/1, default from 4 ranks
+n_slots, hot = (slot_chunk * world, 0) if regions is None else (world * sum(regions), world * regions[0])
 for r in range(world):
     first, last, _ = mg.partition_bounds(nv, world, r)
     a = actives[r]
-    x_pos = torch.where(a, torch.cumsum(a, 0) - 1 + r * slot_chunk, torch.full_like(orders[r], -1)).to(torch.int32)
+    j = torch.cumsum(a, 0) - 1
+    if regions is None:
+        slot = j + r * slot_chunk
+    else:
+        c0, c1 = regions
+        slot = torch.where(j < c0, j + r * c0, j - c0 + hot + r * c1)
+    x_pos = torch.where(a, slot, torch.full_like(orders[r], -1)).to(torch.int32)
     slot_of[first + orders[r]] = x_pos
     if r == me:
         my_x_pos = x_pos
@@ -48,9 +57,8 @@ s_l, d_l = torch.cat(parts_s), torch.cat(parts_d)
 del src, dst, sel, parts_s, parts_d
 rank_l = torch.empty_like(orders[me], dtype=torch.int32)
 rank_l[orders[me]] = torch.arange(last - first, dtype=torch.int32, device="cuda")
-eng = mg.HipEngine(h, props)
 g = eng.make_local_graph(slot_of[s_l.long()], rank_l[(d_l - first).long()] + first, None, first, last, nv,
-                         num_source_slots=slot_chunk * world, x_pos=my_x_pos)
+                         num_source_slots=n_slots, x_pos=my_x_pos, hot_slots=hot)
 n_local_edges = int(s_l.numel())
 del s_l, d_l
 ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
@@ -60,6 +68,7 @@ sess = eng.make_session(g, alpha=0.85, epsilon=0.0, precomputed_vertex_out_weigh
 sess.iterate(3)
 torch.cuda.synchronize()
 it, km = sess.timed_iterate(10)
-print(f"scale {scale}, rank {me} of {world}: {last - first} rows, {n_local_edges} edges, {slot_chunk * world} source slots; "
+print(f"scale {scale}, rank {me} of {world}: {last - first} rows, {n_local_edges} edges, {n_slots} source slots "
+      f"({'one region' if regions is None else f'regions of {hot} + {n_slots - hot} slots'}); "
       f"local iteration {it.mean():.3f} ms (dominant kernel {km.mean():.3f} ms) -> {ne / it.mean() / 1e6:.0f} GTEPS if every "
-      f"rank took this long and the exchange were free; gathered vector {slot_chunk * world * 4 / 1e6:.0f} MB")
+      f"rank took this long and the exchange were free; gathered vector {n_slots * 4 / 1e6:.0f} MB")
