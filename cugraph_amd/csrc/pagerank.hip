@@ -80,9 +80,9 @@ struct XsArgs {
   uint32_t const* ent;
   ValT const* w;             // [n_edges + 4] or nullptr
   int64_t const* unit_off;   // [n_tiles * 8 * n_win + 1]
-  // one 256-byte record per (slice, work item), see xs_records_kernel: everything a workgroup needs
+  // one 512-byte record per (slice, work item), see xs_records_kernel: everything a workgroup needs
   // to start on a piece of a (tile, slice) unit, fetched with one load behind the queue's atomic
-  int64_t const* rec;        // [8][n_items][32]
+  int64_t const* rec;        // [8][n_items][64]
   int64_t const* pbase;      // [n_tiles + 1] first partial of each tile (8 * pieces * rows per tile)
   int n_items;               // work items per slice queue: the pieces of all tiles, biggest tiles first
   int n_win;                 // windows of 2^(32 - row_bits) slice-local positions per slice
@@ -94,10 +94,12 @@ struct XsArgs {
   int64_t row_first, n_rows;
   int n_tiles;
   int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
+  int search_windows; // window of an entry by binary search of the record (more than 16 windows; or forced, for tests)
 };
 
-constexpr int kXsRecWords   = 32;
-constexpr int kXsRegWindows = 16;  // window starts a record carries (kept in scalar registers)
+constexpr int kXsRecWords   = 64;  // one load of the first wave
+constexpr int kXsRegWindows = 16;  // window starts kept in scalar registers (graphs with up to 16 windows)
+constexpr int kXsRecWindows = kXsRecWords - 4;  // window starts a record carries: wide tiles up to this many
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
 struct HubItem {
@@ -586,12 +588,28 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
         int64_t d = uniform64(rec[4 + w]) - abeg;
         wb[w]     = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : d < 0 ? 0u : static_cast<uint32_t>(d);
       }
+      int const n_win = xs.n_win;
       auto window_of = [&](uint32_t pos) {
         uint32_t c = 0;
+        if (!xs.search_windows) {
 #pragma unroll
-        for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
-        for (int w = kXsRegWindows; w < xs.n_win; ++w)  // very large source spaces only
-          c += static_cast<int64_t>(pos) >= xs.unit_off[u0 + w] - abeg ? 1u : 0u;
+          for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
+        } else if (n_win <= kXsRecWindows) {
+          // many windows (a huge source space under wide tiles): binary search of the record in
+          // LDS for the last window that starts at or before the entry
+          int64_t const p = abeg + static_cast<int64_t>(pos);
+          uint32_t lo = 0, hi = static_cast<uint32_t>(n_win) - 1u;  // answer in [lo, hi]
+          while (lo < hi) {
+            uint32_t mid = (lo + hi + 1u) >> 1;
+            if (rec[4 + mid] <= p) lo = mid; else hi = mid - 1u;
+          }
+          c = lo;
+        } else {  // beyond what a record carries (narrow tiles over more than 2^29 slots)
+#pragma unroll
+          for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
+          for (int w = kXsRegWindows; w < n_win; ++w)
+            c += static_cast<int64_t>(pos) >= xs.unit_off[u0 + w] - abeg ? 1u : 0u;
+        }
         return c;
       };
       uint32_t const low_mask = (1u << shift) - 1u;
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT
 
 // One record per (slice, work item): what xs_kernel needs to start on that piece of the unit.
 //  [0] tile | piece << 32 | pieces << 40   [1] first row | rows << 32   [2] offset of its partials
-//  [3] first entry  [4] end of the item's entries  [5..19] start of windows 1..15 (INT64_MAX: none)
+//  [3] first entry  [4] end of the item's entries  [5..63] start of windows 1..59 (INT64_MAX: none)
 // An item covers the windows [win_lo, win_hi) of its unit (all of them, or one region of a
 // partitioned graph's source space) and is piece `piece` of `pieces` of that range; its partials
 // are set k * tile_sets[tile] + item.pset of the tile's sets.
@@ -841,8 +859,7 @@ __global__ void xs_records_kernel(XsItem const* __restrict__ items, int n_items,
     r[2] = pbase[t] + (k * sets + it.pset) * rows;
     r[3] = unit_off[u0 + win_lo];
     r[4] = unit_off[u0 + win_hi];
-    for (int w = 1; w < kXsRegWindows; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
-    for (int w = 4 + kXsRegWindows; w < kXsRecWords; ++w) r[w] = 0;
+    for (int w = 1; w < kXsRecWindows; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
   }
 }
 
@@ -1368,7 +1385,7 @@ int xs_row_bits_for(int64_t minor_space, int slice_shift)
   uint32_t const last_local = xs_slice_local(static_cast<uint32_t>(minor_space - 1), slice_shift) |
                               ((1u << slice_shift) - 1u);
   int row_bits = kXsRowBitsMax;
-  while (row_bits > kXsRowBits && (last_local >> (32 - row_bits)) >= static_cast<uint32_t>(kXsRegWindows)) --row_bits;
+  while (row_bits > kXsRowBits && (last_local >> (32 - row_bits)) >= static_cast<uint32_t>(kXsRecWindows)) --row_bits;
   return row_bits;
 }
 
@@ -1399,12 +1416,14 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // 13 / 14 (512- / 1024-thread workgroups, 64 / 128 KiB of accumulators, tiles of up to 8192 /
   // 16384 rows) were measured at scale 26: 3.8 / 7.0 ms against 2.3 ms for 12 -- kept at 12
   // Rows per tile: as many as the entry format allows.  An entry keeps 32 - row_bits bits of its
-  // source position, the rest is implied by its window, and a record carries 16 window starts: 2^14
-  // rows reach 33 M source ids (or slots), 2^13 rows 67 M, 2^12 rows 134 M (beyond: more windows,
-  // read from memory).  Twice the rows per tile = twice the entries per (tile, slice) unit over the
-  // same sources, so fewer distinct lines per gather instruction, and half the tiles.  Measured
-  // (xs_kernel, 12 / 13 / 14 bits): scale 22 0.190 / 0.146 / 0.129 ms, scale 24 0.503 / 0.457 /
-  // 0.438, scale 26 with compact slots (multi-GPU layout) 2.14 / 1.96 / 1.86.
+  // source position, the rest is implied by its window, and a record carries 59 window starts (up
+  // to 16 windows they live in scalar registers, beyond that an entry's window is found by binary
+  // search of the record in LDS): 2^14 rows reach 123 M source ids (or slots), 2^13 rows 247 M,
+  // 2^12 rows 495 M (beyond: window starts read from memory).  Twice the rows per tile = twice
+  // the entries per (tile, slice) unit over the same sources, so fewer distinct lines per gather
+  // instruction, and half the tiles.  Measured (xs_kernel, 12 / 13 / 14 bits): scale 22 0.190 /
+  // 0.146 / 0.129 ms, scale 24 0.503 / 0.457 / 0.438, scale 26 2.14 / 1.96 / 1.86, scale 28 (52
+  // windows at 14 bits) 12.99 / 11.82 / 10.86.
   char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
   int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
   if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
@@ -2115,6 +2134,8 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   {
     char const* am      = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
     a.xs.affinity_mode = am ? std::atoi(am) : 0;
+    bool const force_search = std::getenv("CUGRAPH_AMD_XS_SEARCH_WINDOWS") != nullptr;
+    a.xs.search_windows = (force_search || (s.xs_on && s.graph->plan->xs_n_win > kXsRegWindows)) ? 1 : 0;
   }
   if (s.xs_on) {
     PullPlan const& plan = *s.graph->plan;
