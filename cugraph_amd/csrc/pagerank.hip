@@ -336,7 +336,7 @@ template <typename OffT, typename ValT, bool WEIGHTED>
 __device__ inline void thread_bucket(IterArgs<OffT, ValT> const& a, Bucket const& b,
                                      Epilogue<OffT, ValT>& ep)
 {
-  constexpr int D = static_cast<int>(kXsMinDegree) - 1;  // longest column of this bucket
+  constexpr int D = static_cast<int>(kXsMinDegree) > 1 ? static_cast<int>(kXsMinDegree) - 1 : 1;  // longest column of this bucket
   constexpr int R = 2;
   int64_t t = (int64_t)(blockIdx.x - b.block_begin) * kThreads + threadIdx.x;
   int64_t n = (int64_t)b.n_blocks * kThreads;
