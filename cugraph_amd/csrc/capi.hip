@@ -77,7 +77,8 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
                   ArrayView const* src_in, ArrayView const* dst_in, ArrayView const* weights_in,
                   bool store_transposed, bool renumber, bool drop_self_loops, bool drop_multi_edges,
                   int64_t vertex_first, int64_t vertex_last, int64_t num_global /* <0: single GPU */,
-                  int64_t num_source_slots = 0, ArrayView const* x_pos = nullptr)
+                  int64_t num_source_slots = 0, ArrayView const* x_pos = nullptr,
+                  bool do_expensive_check = false)
 {
   ArrayView const *src = src_in, *dst = dst_in, *weights = weights_in;
   CGA_EXPECTS(src && dst, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src and dst are required.");
@@ -108,6 +109,9 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
     dst = &fdst;
     if (weights) weights = &fw;
   }
+
+  // create_graph_from_edgelist_impl.cuh:895-900 (graph_checks.hip)
+  if (do_expensive_check && vertices) expensive_check_vertices(h, *vertices, renumber);
 
   hipStream_t stream = h.stream;
   int64_t ne         = static_cast<int64_t>(src->size);
@@ -198,6 +202,8 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
   // multi-GPU driver relabelled) run on contiguous degree buckets without a sorted copy
   if (store_transposed && !g->degree_sorted)
     g->degree_sorted = degrees_descending(stream, g->offsets, g->off64, g->num_vertices);
+  // create_graph_from_edgelist_impl.cuh:902-920, on the graph just built
+  if (do_expensive_check) expensive_check_graph(h, *g);
   return g.release();
 }
 
@@ -487,7 +493,6 @@ cugraph_error_code_t cugraph_graph_create_sg(
   bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t do_expensive_check,
   cugraph_graph_t** graph, cugraph_error_t** error)
 {
-  (void)do_expensive_check;
   if (graph) *graph = nullptr;
   if (error) *error = nullptr;
   if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
@@ -507,7 +512,8 @@ cugraph_error_code_t cugraph_graph_create_sg(
                 "Invalid input arguments: src size != edge type prop size");
     Graph* g = make_graph(*as<Handle>(handle), properties, as<ArrayView>(vertices), s,
                           as<ArrayView>(dst), as<ArrayView>(weights), store_transposed != FALSE,
-                          renumber != FALSE, drop_self_loops != FALSE, drop_multi_edges != FALSE, 0, 0, -1);
+                          renumber != FALSE, drop_self_loops != FALSE, drop_multi_edges != FALSE, 0, 0, -1,
+                          0, nullptr, do_expensive_check != FALSE);
     *graph = reinterpret_cast<cugraph_graph_t*>(g);
   });
 }
@@ -535,7 +541,6 @@ cugraph_error_code_t cugraph_graph_create_sg_from_csr(
   const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed,
   bool_t renumber, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
 {
-  (void)do_expensive_check;
   if (graph) *graph = nullptr;
   if (error) *error = nullptr;
   if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
@@ -569,7 +574,7 @@ cugraph_error_code_t cugraph_graph_create_sg_from_csr(
     }
     ArrayView vv{verts.p, static_cast<size_t>(nv), static_cast<size_t>(nv) * dtype_size(idx->type), idx->type};
     Graph* g = make_graph(h, properties, &vv, &sv, idx, w, store_transposed != FALSE, renumber != FALSE,
-                          false, false, 0, 0, -1);
+                          false, false, 0, 0, -1, 0, nullptr, do_expensive_check != FALSE);
     *graph = reinterpret_cast<cugraph_graph_t*>(g);
   });
 }

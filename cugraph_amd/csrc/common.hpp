@@ -262,6 +262,10 @@ void filter_edgelist(Handle const& h, bool drop_self_loops, bool drop_multi_edge
                      bool renumber, ArrayView const* vertices, ArrayView& src, ArrayView& dst,
                      ArrayView* weights, std::vector<DevBuf>& hold);
 
+// graph_checks.hip: do_expensive_check of the graph build
+void expensive_check_vertices(Handle const& h, ArrayView const& vertices, bool renumber);
+void expensive_check_graph(Handle const& h, Graph const& g);
+
 // out[i] = in[i] - shift  /  out[i] = (int64) in[i]
 void shift_ids(hipStream_t stream, int32_t const* in, int32_t* out, int64_t n, int64_t shift);
 void widen_ids(hipStream_t stream, int32_t const* in, int64_t* out, int64_t n);

@@ -118,3 +118,79 @@ def test_empty_personalization_is_rejected():
     with pytest.raises((ValueError, RuntimeError)):
         plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.zeros(0, np.int32)),
                                   to_dev(np.zeros(0, np.float32)), 0.85, 1e-6, 100, False)
+
+
+def _build(src, dst, *, symmetric=False, multigraph=False, renumber=False, vertices=None, check=True,
+           transposed=True, input_type="COO", id_dtype=np.int32):
+    from cugraph_amd import pylibcugraph as plc
+
+    h = plc.ResourceHandle()
+    props = plc.GraphProperties(is_symmetric=symmetric, is_multigraph=multigraph)
+    return plc.SGGraph(h, props, to_dev(np.asarray(src, id_dtype)), to_dev(np.asarray(dst, id_dtype)),
+                       store_transposed=transposed, renumber=renumber, do_expensive_check=check,
+                       input_array_format=input_type,
+                       vertices_array=None if vertices is None else to_dev(np.asarray(vertices, id_dtype)))
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("renumber", [False, True])
+def test_expensive_check_symmetry(renumber, transposed):
+    """create_graph_from_edgelist_impl.cuh:902-910: a graph flagged symmetric whose edge list is not
+    is refused under do_expensive_check (and only then)."""
+    sym_s, sym_d = [0, 1, 1, 2, 3], [1, 0, 2, 1, 3]  # a self-loop is its own reverse
+    _build(sym_s, sym_d, symmetric=True, renumber=renumber, transposed=transposed)
+    with pytest.raises(RuntimeError, match="is_symmetric is true but the input edge list is not symmetric"):
+        _build(sym_s + [0], sym_d + [3], symmetric=True, renumber=renumber, transposed=transposed)
+    # every edge has a reverse, but not as many copies of it
+    with pytest.raises(RuntimeError, match="not symmetric"):
+        _build([0, 0, 1], [1, 1, 0], symmetric=True, multigraph=True, renumber=renumber, transposed=transposed)
+    _build([0, 0, 1, 1], [1, 1, 0, 0], symmetric=True, multigraph=True, renumber=renumber, transposed=transposed)
+    _build(sym_s + [0], sym_d + [3], symmetric=True, renumber=renumber, transposed=transposed, check=False)
+    _build(sym_s + [0], sym_d + [3], symmetric=False, renumber=renumber, transposed=transposed)
+
+
+@pytest.mark.parametrize("renumber", [False, True])
+def test_expensive_check_parallel_edges(renumber):
+    """create_graph_from_edgelist_impl.cuh:912-920"""
+    rng = np.random.default_rng(5)
+    n = 3000
+    pairs = np.unique(rng.integers(0, n, size=(40000, 2)), axis=0)
+    rng.shuffle(pairs)
+    src, dst = pairs[:, 0], pairs[:, 1]
+    _build(src, dst, renumber=renumber)
+    s2, d2 = np.append(src, src[1234]), np.append(dst, dst[1234])
+    with pytest.raises(RuntimeError, match="is_multigraph is false but the input edge list has parallel edges"):
+        _build(s2, d2, renumber=renumber)
+    _build(s2, d2, multigraph=True, renumber=renumber)
+    _build(s2, d2, renumber=renumber, check=False)
+    # symmetry is tested before parallel edges (:902 before :912)
+    with pytest.raises(RuntimeError, match="not symmetric"):
+        _build([0, 0, 1], [1, 1, 0], symmetric=True, renumber=renumber)
+
+
+@pytest.mark.parametrize("id_dtype", [np.int32, np.int64])
+def test_expensive_check_vertex_list(id_dtype):
+    """create_graph_from_edgelist_impl.cuh:79-108"""
+    src, dst = [0, 1, 2], [1, 2, 0]
+    _build(src, dst, vertices=[0, 1, 2, 3], id_dtype=id_dtype)
+    _build([10, 30], [30, 50], vertices=[50, 30, 10, 70], renumber=True, id_dtype=id_dtype)
+    for renumber in (False, True):
+        with pytest.raises(RuntimeError, match="vertices should not have duplicates"):
+            _build(src, dst, vertices=[0, 1, 2, 2], renumber=renumber, id_dtype=id_dtype)
+        with pytest.raises(RuntimeError, match="vertices should not have duplicates"):
+            _build(src, dst, vertices=[0, 1, 2, 900, 900], renumber=renumber, id_dtype=id_dtype)
+    with pytest.raises(RuntimeError, match="consecutive integers starting from 0"):
+        _build(src, dst, vertices=[0, 1, 2, 4], id_dtype=id_dtype)
+    with pytest.raises(RuntimeError, match="consecutive integers starting from 0"):
+        _build([1, 2], [2, 3], vertices=[1, 2, 3], id_dtype=id_dtype)
+    with pytest.raises(RuntimeError, match=r"vertex IDs should be in \[0, "):
+        _build(src, dst, vertices=[-1, 0, 1, 2], id_dtype=id_dtype)
+
+
+def test_expensive_check_csr_input():
+    """graph_sg.cpp:262-430: the CSR path hands do_expensive_check to the same build"""
+    off, idx = [0, 2, 3, 3], [1, 1, 2]  # row 0 holds 0->1 twice
+    with pytest.raises(RuntimeError, match="parallel edges"):
+        _build(off, idx, input_type="CSR", transposed=False)
+    _build(off, idx, input_type="CSR", transposed=False, multigraph=True)
+    _build(off, idx, input_type="CSR", transposed=False, check=False)
