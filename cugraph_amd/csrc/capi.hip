@@ -166,6 +166,10 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
     renumber_edgelist(h, *g, vertices, src, dst, store_transposed, s32.as<int32_t>(),
                       d32.as<int32_t>());
     n_major = n_minor = g->num_vertices;
+    // create_graph_from_edgelist_impl.cuh:84-89, for id spans expensive_check_vertices cannot table
+    CGA_EXPECTS(!(do_expensive_check && vertices) ||
+                  g->num_vertices == static_cast<int64_t>(vertices->size),
+                CUGRAPH_UNKNOWN_ERROR, "Invalid input argument: vertices should not have duplicates.");
   } else {
     // create_graph_from_edgelist_impl.cuh:939-949
     int64_t nv = vertices ? static_cast<int64_t>(vertices->size)

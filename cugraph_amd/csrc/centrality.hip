@@ -108,17 +108,13 @@ __global__ void scatter_kernel(T const* in, int32_t const* order, int64_t n, T* 
   GRID_STRIDE(i, n) out[order[i]] = in[i];
 }
 template <typename IdT, typename T>
-__global__ void scatter_pairs_kernel(IdT const* ids, T const* vals, int64_t n, int32_t const* lookup,
-                                     long long ext_min, long long ext_range, long long count, T* dense,
-                                     unsigned int* bad)
+__global__ void scatter_pairs_kernel(IdT const* ids, T const* vals, int64_t n, ExtLookup ext,
+                                     long long count, T* dense, unsigned int* bad)
 {
   GRID_STRIDE(i, n)
   {
     long long v = static_cast<long long>(ids[i]);
-    if (lookup) {
-      long long k = v - ext_min;
-      v           = (k >= 0 && k < ext_range) ? lookup[k] : -1;
-    }
+    if (ext.lookup) v = ext.find(v);
     if (v < 0 || v >= count)
       atomicAdd(bad, 1u);
     else
@@ -216,12 +212,12 @@ void dense_from_pairs(Handle const& h, Graph& g, ArrayView const& ids, ArrayView
   if (ids.type == INT64)
     hipLaunchKernelGGL((scatter_pairs_kernel<int64_t, T>), dim3(grid_for(n)), dim3(kThreads), 0, h.stream,
                        static_cast<int64_t const*>(ids.data), static_cast<T const*>(vals.data), n,
-                       g.ext_lookup, (long long)g.ext_min, (long long)g.ext_range,
+                       ExtLookup{g.ext_lookup, g.ext_min, g.ext_range, g.ext_sorted},
                        (long long)g.num_vertices, dense, bad.as<unsigned int>());
   else
     hipLaunchKernelGGL((scatter_pairs_kernel<int32_t, T>), dim3(grid_for(n)), dim3(kThreads), 0, h.stream,
                        static_cast<int32_t const*>(ids.data), static_cast<T const*>(vals.data), n,
-                       g.ext_lookup, (long long)g.ext_min, (long long)g.ext_range,
+                       ExtLookup{g.ext_lookup, g.ext_min, g.ext_range, g.ext_sorted},
                        (long long)g.num_vertices, dense, bad.as<unsigned int>());
   unsigned int h_bad = 0;
   CGA_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, h.stream));

@@ -137,6 +137,31 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// position of `id` in an ascending array of distinct ids, -1 if absent
+__host__ __device__ inline int64_t find_sorted(long long const* sorted, int64_t n, long long id)
+{
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = lo + (hi - lo) / 2;
+    if (sorted[mid] < id) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && sorted[lo] == id) ? lo : -1;
+}
+
+// external id -> id in a renumbered graph (-1: not a vertex): direct-address table over
+// [min, min + range), or a search of the sorted distinct ids when the graph keeps those
+struct ExtLookup {
+  int32_t const* lookup;
+  int64_t min, range;
+  long long const* sorted;
+  __host__ __device__ inline int64_t find(int64_t id) const
+  {
+    int64_t k = sorted ? find_sorted(sorted, range, id) : id - min;
+    if (k < 0 || k >= range) return -1;
+    return lookup[k];
+  }
+};
+
 // ---------------------------------------------------------------- graph
 // Compressed sparse graph.  Majors are dst when store_transposed (CSC, the pull layout PageRank
 // wants), src otherwise.  Indices are always int32 internally (V < 2^31); offsets are int32 while
@@ -175,6 +200,9 @@ struct Graph {
   int32_t* ext_lookup{nullptr};
   int64_t ext_min{0};
   int64_t ext_range{0};
+  // ids spanning 2^31 or more (renumber.hip, renumber_sparse_ids): the distinct external ids in
+  // ascending order [num_vertices]; then ext_lookup is indexed by the POSITION of an id in it
+  long long* ext_sorted{nullptr};
 
   PullPlan* plan{nullptr};  // cached by the first PageRank call on this graph
   Graph* reversed{nullptr};  // the other orientation without weights, cached by the first HITS call

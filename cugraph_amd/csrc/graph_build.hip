@@ -640,6 +640,7 @@ Graph::~Graph()
   if (weights) (void)hipFree(weights);
   if (number_map) (void)hipFree(number_map);
   if (ext_lookup) (void)hipFree(ext_lookup);
+  if (ext_sorted) (void)hipFree(ext_sorted);
   if (x_pos) (void)hipFree(x_pos);
   if (plan) destroy_plan(plan);
   delete reversed;

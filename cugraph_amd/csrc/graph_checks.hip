@@ -134,7 +134,9 @@ void expensive_check_vertices(Handle const& h, ArrayView const& vertices, bool r
   long long h_mm[2];
   CGA_HIP(hipMemcpyAsync(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
-  long long const lo = h_mm[0], range = h_mm[1] - h_mm[0] + 1;
+  // (unsigned: 64-bit ids can span more than the signed range; such a list goes on as "wide")
+  unsigned long long const span = static_cast<unsigned long long>(h_mm[1]) - static_cast<unsigned long long>(h_mm[0]);
+  long long const lo = h_mm[0], range = span < 0x7ffffffeull ? static_cast<long long>(span) + 1 : 0x7fffffffLL;
   // n ids over fewer than n distinct values: duplicates, whatever the values are
   bool duplicates = range < n;
   if (!duplicates && range < 0x7fffffffLL) {
@@ -157,8 +159,8 @@ void expensive_check_vertices(Handle const& h, ArrayView const& vertices, bool r
     CGA_HIP(hipStreamSynchronize(stream));
     duplicates = static_cast<int64_t>(distinct) < n;
   }
-  // (ids spanning 2^31 or more: a list without renumbering fails the checks below, one with
-  // renumbering is refused by the renumbering itself)
+  // (ids spanning 2^31 or more: a list without renumbering fails the checks below; under
+  // renumbering the caller compares the number of distinct ids the renumbering found, make_graph)
   CGA_EXPECTS(!duplicates, CUGRAPH_UNKNOWN_ERROR,
               "Invalid input argument: vertices should not have duplicates.");
   if (!renumber) {

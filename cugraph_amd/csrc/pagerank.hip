@@ -1152,6 +1152,7 @@ __global__ void source_sums_kernel(int32_t const* __restrict__ indices,
 struct IdMap {
   int32_t const* lookup0;  // graph's own renumber map (external -> graph id), or nullptr
   int64_t min0, range0;
+  long long const* sorted0;  // not nullptr: lookup0 is indexed by the id's position in these sorted ids
   int32_t const* lookup1;  // plan's degree-sort permutation (graph id -> plan row), or nullptr
   int64_t first;           // first global id of the local range (no lookup0)
   int64_t count;           // rows
@@ -1159,9 +1160,7 @@ struct IdMap {
   {
     int64_t v;
     if (lookup0) {
-      int64_t k = id - min0;
-      if (k < 0 || k >= range0) return -1;
-      v = lookup0[k];
+      v = ExtLookup{lookup0, min0, range0, sorted0}.find(id);
       if (v < 0) return -1;
     } else {
       v = id - first;
@@ -1926,6 +1925,7 @@ void session_setup(Session& s, PagerankArgs const& a)
   idmap.lookup0 = s.graph->ext_lookup;
   idmap.min0    = s.graph->ext_min;
   idmap.range0  = s.graph->ext_range;
+  idmap.sorted0 = s.graph->ext_sorted;
   idmap.lookup1 = plan.internal ? plan.internal->ext_lookup : nullptr;
   idmap.first   = s.graph->vertex_first;
   idmap.count   = nl;

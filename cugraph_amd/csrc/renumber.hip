@@ -6,7 +6,8 @@
 // vertex set from E-sized sorts + merges, its degrees from sort + reduce_by_key, orders by
 // sort_by_key(greater) and relabels through a cuco hash map.  Here:
 //   - the vertex set comes from a direct-address flag table over [min id, max id] + one scan
-//     (ids must span less than 2^31; hashed ids wider than that are NOT_IMPLEMENTED);
+//     while the ids span less than 2^31; wider id spaces (hashed 64-bit ids) go through an
+//     open-addressing hash set of the distinct ids, which are then sorted and searched;
 //   - degrees come from the same histogram kernel as the CSC build;
 //   - the order is a stable LSD radix split, one bit per pass (flag + scan + scatter), so the
 //     result is deterministic;
@@ -49,6 +50,11 @@ __global__ void max_u32_kernel(unsigned int const* v, int64_t n, unsigned int* o
 }
 
 __global__ void iota_kernel(int32_t* v, int64_t n) { GRID_STRIDE(i, n) v[i] = (int32_t)i; }
+
+__global__ void fill_u64_kernel(unsigned long long* v, int64_t n, unsigned long long value)
+{
+  GRID_STRIDE(i, n) v[i] = value;
+}
 
 __global__ void bit_flag_kernel(unsigned int const* keys, int64_t n, int bit, unsigned int* flags)
 {
@@ -126,6 +132,102 @@ __global__ void number_map_kernel(int64_t range, long long lo, unsigned int cons
       lookup[k] = -1;
     }
   }
+}
+
+// ---- ids spanning 2^31 or more: distinct ids through a hash set, then sorted
+constexpr unsigned long long kEmptySlot = 0x8000000000000000ull;  // INT64_MIN: never a legal id here
+
+__device__ inline unsigned long long mix64(unsigned long long x)
+{
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+  return x ^ (x >> 33);
+}
+
+template <typename IdT>
+__global__ void hash_insert_kernel(IdT const* __restrict__ ids, int64_t n, unsigned long long* table,
+                                   unsigned long long mask, unsigned int* saw_sentinel)
+{
+  GRID_STRIDE(i, n)
+  {
+    unsigned long long const v = static_cast<unsigned long long>(static_cast<long long>(ids[i]));
+    if (v == kEmptySlot) {
+      *saw_sentinel = 1u;
+      continue;
+    }
+    unsigned long long h = mix64(v) & mask;
+    // the table has at least twice as many slots as keys: a probe always ends
+    while (true) {
+      unsigned long long const old = atomicCAS(&table[h], kEmptySlot, v);
+      if (old == kEmptySlot || old == v) break;
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+__global__ void slot_used_kernel(unsigned long long const* __restrict__ table, int64_t n, unsigned int* flags)
+{
+  GRID_STRIDE(i, n) flags[i] = table[i] != kEmptySlot ? 1u : 0u;
+}
+
+// occupied slots -> keys biased by the smallest id (so that unsigned order = id order)
+__global__ void slot_compact_kernel(unsigned long long const* __restrict__ table, int64_t n,
+                                    int64_t const* __restrict__ pos, unsigned long long lo,
+                                    unsigned long long* __restrict__ keys)
+{
+  GRID_STRIDE(i, n)
+  {
+    unsigned long long v = table[i];
+    if (v != kEmptySlot) keys[pos[i]] = v - lo;
+  }
+}
+
+__global__ void bit_flag64_kernel(unsigned long long const* keys, int64_t n, int bit, unsigned int* flags)
+{
+  GRID_STRIDE(i, n) flags[i] = static_cast<unsigned int>((keys[i] >> bit) & 1ull);
+}
+
+// stable split, zeros first (ascending order)
+__global__ void bit_split64_kernel(unsigned long long const* keys_in, int64_t n, int bit,
+                                   int64_t const* ones_before, unsigned long long* keys_out)
+{
+  int64_t const total_zeros = n - ones_before[n];
+  GRID_STRIDE(i, n)
+  {
+    unsigned long long k = keys_in[i];
+    int64_t ob           = ones_before[i];
+    keys_out[((k >> bit) & 1ull) ? total_zeros + ob : i - ob] = k;
+  }
+}
+
+// sorted biased keys -> the ids themselves (int64)
+__global__ void unbias_kernel(unsigned long long const* keys, int64_t n, unsigned long long lo, long long* ids)
+{
+  GRID_STRIDE(i, n) ids[i] = static_cast<long long>(keys[i] + lo);
+}
+
+// endpoint -> its position in the sorted distinct ids
+template <typename IdT>
+__global__ void to_dense_sorted_kernel(IdT const* __restrict__ ids, int64_t n,
+                                       long long const* __restrict__ sorted, int64_t n_sorted,
+                                       int32_t* __restrict__ out, unsigned int* n_unknown)
+{
+  GRID_STRIDE(i, n)
+  {
+    int64_t k = find_sorted(sorted, n_sorted, static_cast<long long>(ids[i]));
+    if (k < 0) {
+      atomicAdd(n_unknown, 1u);
+      k = 0;
+    }
+    out[i] = static_cast<int32_t>(k);
+  }
+}
+
+template <typename IdT>
+__global__ void number_map_sorted_kernel(long long const* __restrict__ sorted, int64_t n,
+                                         int32_t const* __restrict__ rank, IdT* __restrict__ number_map)
+{
+  GRID_STRIDE(k, n) number_map[rank[k]] = static_cast<IdT>(sorted[k]);
 }
 
 template <typename IdT>
@@ -372,6 +474,146 @@ Graph* degree_sorted_copy(Handle const& h, Graph const& g)
 // renumber=TRUE: arbitrary external ids (vertex_type) -> degree-sorted dense ids.
 // On return src32/dst32 hold the relabelled endpoints, g.number_map / ext_lookup are set and
 // g.num_vertices is the number of distinct vertices.
+namespace {
+// renumber_edgelist for ids that span 2^31 or more (no direct-address table): the distinct ids are
+// collected in a hash set, sorted, and every endpoint finds its dense (ascending-id) label by
+// binary search -- the same labels the table path gives, so everything after it is shared.
+void renumber_sparse_ids(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
+                         ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32,
+                         long long lo, unsigned long long span)
+{
+  hipStream_t stream = h.stream;
+  int64_t const ne   = static_cast<int64_t>(src->size);
+  bool const wide    = src->type == INT64;
+  int64_t const n_keys = vertices ? static_cast<int64_t>(vertices->size) : 2 * ne;
+  unsigned long long slots = 1024;
+  while (slots < 2ull * static_cast<unsigned long long>(n_keys)) slots <<= 1;
+  DevBuf table(slots * 8), saw(4);
+  CGA_HIP(hipMemsetAsync(saw.p, 0, 4, stream));
+  {
+    // every slot = kEmptySlot: only the top byte of each 8 is set
+    DevBuf& t = table;
+    CGA_HIP(hipMemsetAsync(t.p, 0, t.bytes, stream));
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(static_cast<int64_t>(slots))), dim3(kThreads), 0, stream,
+                       t.as<unsigned long long>(), static_cast<int64_t>(slots), kEmptySlot);
+  }
+  auto insert = [&](ArrayView const* a) {
+    if (!a || a->size == 0) return;
+    int64_t n = static_cast<int64_t>(a->size);
+    if (wide)
+      hipLaunchKernelGGL((hash_insert_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(a->data), n, table.as<unsigned long long>(), slots - 1,
+                         saw.as<unsigned int>());
+    else
+      hipLaunchKernelGGL((hash_insert_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(a->data), n, table.as<unsigned long long>(), slots - 1,
+                         saw.as<unsigned int>());
+  };
+  if (vertices) {
+    insert(vertices);
+  } else {
+    insert(src);
+    insert(dst);
+  }
+  DevBuf used(slots * 4), upos((slots + 1) * 8);
+  hipLaunchKernelGGL(slot_used_kernel, dim3(grid_for(static_cast<int64_t>(slots))), dim3(kThreads), 0, stream,
+                     table.as<unsigned long long>(), static_cast<int64_t>(slots), used.as<unsigned int>());
+  exclusive_scan_u32_to_i64(stream, used.as<unsigned int>(), static_cast<int64_t>(slots), upos.as<int64_t>());
+  int64_t nv             = 0;
+  unsigned int h_saw     = 0;
+  CGA_HIP(hipMemcpyAsync(&nv, upos.as<int64_t>() + slots, 8, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipMemcpyAsync(&h_saw, saw.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  CGA_EXPECTS(h_saw == 0, CUGRAPH_NOT_IMPLEMENTED, "renumber=TRUE: the smallest 64-bit integer as a vertex id");
+  CGA_EXPECTS(nv < 0x7fffffffLL, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "2^31 or more vertices are not supported");
+  size_t const nn = static_cast<size_t>(nv > 0 ? nv : 1);
+  DevBuf keys_a(nn * 8), keys_b(nn * 8);
+  hipLaunchKernelGGL(slot_compact_kernel, dim3(grid_for(static_cast<int64_t>(slots))), dim3(kThreads), 0, stream,
+                     table.as<unsigned long long>(), static_cast<int64_t>(slots), upos.as<int64_t>(),
+                     static_cast<unsigned long long>(lo), keys_a.as<unsigned long long>());
+  table.release();
+  used.release();
+  upos.release();
+  // ---- ascending order: stable one-bit splits over the bits the span has
+  {
+    DevBuf flags(nn * 4), pos((nn + 1) * 8);
+    unsigned long long* kin  = keys_a.as<unsigned long long>();
+    unsigned long long* kout = keys_b.as<unsigned long long>();
+    int bits = 0;
+    while (bits < 64 && (span >> bits) != 0) ++bits;
+    for (int b = 0; b < bits && nv > 1; ++b) {
+      hipLaunchKernelGGL(bit_flag64_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, kin, nv, b,
+                         flags.as<unsigned int>());
+      exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), nv, pos.as<int64_t>());
+      hipLaunchKernelGGL(bit_split64_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, kin, nv, b,
+                         pos.as<int64_t>(), kout);
+      std::swap(kin, kout);
+    }
+    if (kin != keys_a.as<unsigned long long>())
+      CGA_HIP(hipMemcpyAsync(keys_a.p, kin, nn * 8, hipMemcpyDeviceToDevice, stream));
+  }
+  DevBuf sorted(nn * 8);
+  if (nv > 0)
+    hipLaunchKernelGGL(unbias_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream,
+                       keys_a.as<unsigned long long>(), nv, static_cast<unsigned long long>(lo),
+                       sorted.as<long long>());
+  keys_a.release();
+  keys_b.release();
+  // ---- endpoints -> dense (ascending-id) labels
+  DevBuf unknown(4);
+  CGA_HIP(hipMemsetAsync(unknown.p, 0, 4, stream));
+  auto densify = [&](ArrayView const* a, int32_t* out) {
+    if (a->size == 0) return;
+    int64_t n = static_cast<int64_t>(a->size);
+    if (wide)
+      hipLaunchKernelGGL((to_dense_sorted_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(a->data), n, sorted.as<long long>(), nv, out,
+                         unknown.as<unsigned int>());
+    else
+      hipLaunchKernelGGL((to_dense_sorted_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(a->data), n, sorted.as<long long>(), nv, out,
+                         unknown.as<unsigned int>());
+  };
+  densify(src, src32);
+  densify(dst, dst32);
+  unsigned int h_unknown = 0;
+  CGA_HIP(hipMemcpyAsync(&h_unknown, unknown.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  CGA_EXPECTS(h_unknown == 0, CUGRAPH_INVALID_INPUT,
+              "Invalid input arguments: edge endpoints missing from the vertex list.");
+  // ---- major degrees, order, relabel (as in renumber_edgelist)
+  DevBuf deg(nn * 4);
+  CGA_HIP(hipMemsetAsync(deg.p, 0, deg.bytes, stream));
+  if (ne > 0)
+    hipLaunchKernelGGL(hist_u32_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                       majors_are_dst ? dst32 : src32, ne, deg.as<unsigned int>());
+  DevBuf order, rank;
+  degree_order_sources_first(stream, deg.as<unsigned int>(), majors_are_dst ? src32 : dst32, ne, nv, order, rank);
+  relabel_ids(stream, src32, ne, rank.as<int32_t>());
+  relabel_ids(stream, dst32, ne, rank.as<int32_t>());
+  // ---- number_map (new -> external); external -> new = search of `sorted`, then rank
+  DevBuf nmap(nn * dtype_size(g.vertex_type));
+  if (nv > 0) {
+    if (wide)
+      hipLaunchKernelGGL((number_map_sorted_kernel<int64_t>), dim3(grid_for(nv)), dim3(kThreads), 0, stream,
+                         sorted.as<long long>(), nv, rank.as<int32_t>(), nmap.as<int64_t>());
+    else
+      hipLaunchKernelGGL((number_map_sorted_kernel<int32_t>), dim3(grid_for(nv)), dim3(kThreads), 0, stream,
+                         sorted.as<long long>(), nv, rank.as<int32_t>(), nmap.as<int32_t>());
+  }
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));
+  g.num_vertices = g.num_global_vertices = nv;
+  g.renumbered    = true;
+  g.degree_sorted = true;
+  g.number_map    = nmap.detach();
+  g.ext_lookup    = static_cast<int32_t*>(rank.detach());
+  g.ext_sorted    = static_cast<long long*>(sorted.detach());
+  g.ext_min       = 0;
+  g.ext_range     = nv;
+}
+}  // namespace
+
 void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
                        ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32)
 {
@@ -400,9 +642,16 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
   CGA_HIP(hipStreamSynchronize(stream));
   bool empty = h_mm[1] < h_mm[0];
   long long lo = empty ? 0 : h_mm[0];
-  long long range = empty ? 0 : h_mm[1] - h_mm[0] + 1;
-  CGA_EXPECTS(range < 0x7fffffffLL, CUGRAPH_NOT_IMPLEMENTED,
-              "renumber=TRUE: vertex ids must span less than 2^31 (max id - min id)");
+  // (unsigned: the span of 64-bit ids can exceed the signed range)
+  unsigned long long const span = empty ? 0ull
+                                        : static_cast<unsigned long long>(h_mm[1]) -
+                                            static_cast<unsigned long long>(h_mm[0]);
+  bool const sparse = span >= 0x7ffffffeull || (!empty && std::getenv("CUGRAPH_AMD_RENUMBER_SPARSE") != nullptr);
+  if (sparse) {
+    renumber_sparse_ids(h, g, vertices, src, dst, majors_are_dst, src32, dst32, lo, span);
+    return;
+  }
+  long long range = empty ? 0 : static_cast<long long>(span) + 1;
   size_t rr = static_cast<size_t>(range > 0 ? range : 1);
   // ---- vertex set: the given list, or every endpoint
   DevBuf flags(rr * 4), pos((rr + 1) * 8);

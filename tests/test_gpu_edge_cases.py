@@ -179,6 +179,13 @@ def test_expensive_check_vertex_list(id_dtype):
             _build(src, dst, vertices=[0, 1, 2, 2], renumber=renumber, id_dtype=id_dtype)
         with pytest.raises(RuntimeError, match="vertices should not have duplicates"):
             _build(src, dst, vertices=[0, 1, 2, 900, 900], renumber=renumber, id_dtype=id_dtype)
+    if id_dtype == np.int64:  # ids too far apart for a table: found by the renumbering's distinct count
+        big = 1 << 60
+        _build([-big, 5], [5, big], vertices=[-big, 5, big], renumber=True, id_dtype=id_dtype)
+        with pytest.raises(RuntimeError, match="vertices should not have duplicates"):
+            _build([-big, 5], [5, big], vertices=[-big, 5, big, 5], renumber=True, id_dtype=id_dtype)
+        with pytest.raises(RuntimeError, match="consecutive integers starting from 0"):
+            _build([0, 1], [1, 0], vertices=[0, 1, big], id_dtype=id_dtype)
     with pytest.raises(RuntimeError, match="consecutive integers starting from 0"):
         _build(src, dst, vertices=[0, 1, 2, 4], id_dtype=id_dtype)
     with pytest.raises(RuntimeError, match="consecutive integers starting from 0"):

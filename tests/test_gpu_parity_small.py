@@ -310,6 +310,93 @@ def test_renumber_true_external_ids(name, id_dtype, transposed):
     assert np.max(np.abs(got - o_pr)) <= 2e-6
 
 
+@pytest.mark.parametrize("ids", ["forced", "wide64", "wide64_no_list", "full_int32"])
+@pytest.mark.parametrize("transposed", [True, False])
+def test_renumber_ids_spanning_more_than_int31(ids, transposed, monkeypatch):
+    """External ids whose span does not fit a direct-address table (hashed 64-bit ids; int32 ids from
+    one end of the type to the other) are renumbered through the hash set + sorted-id search
+    (renumber.hip, renumber_sparse_ids): same numbering rule as the table path (descending major
+    degree, ties by ascending external id), number_map and results in external ids, and
+    personalization / initial guess given in external ids."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    src, dst, wgt = load_csv("netscience.csv")
+    nv = int(max(src.max(), dst.max())) + 1
+    rng = np.random.default_rng(17)
+    if ids == "forced":  # the table path's ids, pushed through the other path: identical numbering
+        ext = (np.arange(nv, dtype=np.int64) * 7 - 50).astype(np.int32)
+        g0, h0 = make_sg_graph(ext[src], ext[dst], wgt, store_transposed=transposed, renumber=True, vertices=ext)
+        want_nmap = compressed_arrays(g0, h0)[3]
+        monkeypatch.setenv("CUGRAPH_AMD_RENUMBER_SPARSE", "1")
+    elif ids == "full_int32":
+        ext = np.unique(rng.integers(-2**31, 2**31 - 1, size=4 * nv, dtype=np.int64))[:nv]
+        ext = rng.permutation(ext).astype(np.int32)
+        ext[0], ext[1] = -2**31, 2**31 - 1
+    else:
+        ext = np.unique(rng.integers(-2**62, 2**62, size=4 * nv, dtype=np.int64))[:nv]
+        ext = rng.permutation(ext)
+        ext[0], ext[1] = -2**63 + 1, 2**63 - 1
+    no_list = ids == "wide64_no_list"
+    g, h = make_sg_graph(ext[src], ext[dst], wgt, store_transposed=transposed, renumber=True,
+                         vertices=None if no_list else ext)
+    touched = np.zeros(nv, bool)
+    touched[src] = True
+    touched[dst] = True
+    n_expected = int(touched.sum()) if no_list else nv
+    assert g.info()["renumbered"] == 1 and g.info()["num_vertices"] == n_expected
+    off, idx, w, nmap = compressed_arrays(g, h)
+    assert nmap.dtype == ext.dtype
+    assert sorted(nmap.tolist()) == sorted((ext[touched] if no_list else ext).tolist())
+    if ids == "forced":
+        assert np.array_equal(nmap, want_nmap)
+    inv_ext = {int(e): i for i, e in enumerate(ext)}
+    orig = np.array([inv_ext[int(e)] for e in nmap])  # original id of each stored row
+    deg = np.diff(off)
+    assert np.all(deg[:-1] >= deg[1:])
+    is_minor = np.zeros(nv, bool)
+    is_minor[(src if transposed else dst)] = True
+    key2 = np.where(deg > 0, 1, is_minor[orig].astype(int))
+    same = (deg[:-1] == deg[1:]) & (key2[:-1] == key2[1:])
+    assert np.all(nmap[:-1][same] < nmap[1:][same])
+    # stored structure == oracle CSC of the relabelled edge list
+    inv = {int(e): i for i, e in enumerate(nmap)}
+    s2 = np.array([inv[int(e)] for e in ext[src]], np.int32)
+    d2 = np.array([inv[int(e)] for e in ext[dst]], np.int32)
+    major, minor = (d2, s2) if transposed else (s2, d2)
+    o_off, o_idx, o_w = oracle.csc_lexsort(n_expected, minor, major, wgt)
+    assert np.array_equal(off.astype(np.int64), o_off) and np.array_equal(idx, o_idx)
+    assert np.array_equal(w, o_w)
+    # PageRank, personalization and initial guess in external ids
+    pv_orig = np.unique(np.concatenate([src[:50], dst[:50]]))[:3]
+    pvals = np.array([0.2, 0.5, 0.3], np.float32)
+    gv_orig = np.flatnonzero(touched) if no_list else np.arange(nv)
+    gvals = np.full(len(gv_orig), 1.0 / len(gv_orig), np.float32)
+    v, r = plc.personalized_pagerank(h, g, None, None, to_dev(ext[gv_orig]), to_dev(gvals), to_dev(ext[pv_orig]),
+                                     to_dev(pvals), 0.85, 1e-7, 500, False)
+    # the oracle runs on the graph in stored order (vertices no edge mentions do not exist without a list)
+    c_off, c_idx, perm = oracle.compress(n_expected, d2, s2)
+    pers_rows = np.array([inv[int(e)] for e in ext[pv_orig]])
+    # equal personalization ids add up (pagerank.cpp:127-156 routes pairs, the kernel accumulates)
+    o_pr, _, _ = oracle.pagerank(n_expected, c_off, c_idx, wgt[perm], dtype=np.float64, alpha=0.85,
+                                 epsilon=1e-7, max_iterations=500,
+                                 nstart=np.full(n_expected, 1.0 / len(gv_orig)),
+                                 pers_vertices=pers_rows, pers_values=pvals)
+    v = v.cpu().numpy()
+    assert v.dtype == ext.dtype and np.array_equal(v, nmap)
+    assert np.max(np.abs(r.cpu().numpy() - o_pr)) <= 2e-6
+    # an id that is not a vertex is refused, on both sides of the sorted range
+    for bad in (int(ext.max()) - 1, int(ext.min()) + 1):
+        if bad in inv:
+            continue
+        with pytest.raises(ValueError):
+            plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.array([bad], ext.dtype)),
+                                      to_dev(np.array([1.0], np.float32)), 0.85, 1e-6, 100, False)
+    if not no_list:  # an endpoint the vertex list does not hold
+        with pytest.raises(ValueError, match="missing from the vertex list"):
+            make_sg_graph(ext[src], ext[dst], wgt, store_transposed=transposed, renumber=True, vertices=ext[:-5])
+
+
 def test_unknown_vertex_ids_rejected():
     from cugraph_amd import pylibcugraph as plc
 
