@@ -309,11 +309,48 @@ class MGPagerank:
         v = (self.rank_local[(v[keep] - self.first).long()] + self.first).to(self.vertex_dtype)
         return v.contiguous(), (x[keep] / scale).to(self.value_dtype).contiguous()
 
-    def session(self, *, alpha=0.85, epsilon=1e-6, nstart=None, personalization=None):
-        """nstart / personalization: optional (vertices, values) pairs, the SAME on every rank.
+    def _replicated(self, pairs):
+        """Per-rank shards of (vertex, value) pairs -> the whole list on every rank: the sizes are
+        all-gathered, then the shards padded to the longest.  The reference shuffles each pair to
+        the rank that owns its vertex (c_api/pagerank.cpp:140-144); the lists are short (or V-sized
+        at most), so here every rank sees them all and _local_pairs keeps its own."""
+        import torch
+
+        dist = _dist()
+        dev = self.engine.device
+        v = torch.as_tensor(pairs[0], device=dev).to(torch.int64).reshape(-1)
+        x = torch.as_tensor(pairs[1], device=dev).to(torch.float64).reshape(-1)
+        if v.numel() != x.numel():
+            raise ValueError("vertices and values of a (vertex, value) list must have the same length")
+        if self.world == 1:
+            return v, x
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        sizes[self.rank] = v.numel()
+        dist.all_reduce(sizes, group=self.group)
+        longest = int(sizes.max())
+        if longest == 0:
+            return v, x
+        all_v = torch.zeros(self.world * longest, dtype=torch.int64, device=dev)
+        all_x = torch.zeros(self.world * longest, dtype=torch.float64, device=dev)
+        all_v[self.rank * longest:self.rank * longest + v.numel()] = v
+        all_x[self.rank * longest:self.rank * longest + x.numel()] = x
+        all_gather_in_place(all_v, longest, self.rank, self.world, self.group)
+        all_gather_in_place(all_x, longest, self.rank, self.world, self.group)
+        keep = (torch.arange(longest, device=dev)[None, :] < sizes[:, None]).reshape(-1)
+        return all_v[keep], all_x[keep]
+
+    def session(self, *, alpha=0.85, epsilon=1e-6, nstart=None, personalization=None, sharded=False):
+        """nstart / personalization: optional (vertices, values) pairs -- the SAME on every rank,
+        or with sharded=True any share of the list on each rank (a vertex need not be given to the
+        rank that owns it; every rank must make the call, an empty share is fine), as the
+        reference's MG entry takes them (mg_pagerank_test.c:67-94).
         Personalization values are divided by their global sum here (the library normalises only
         what it can see, pagerank_impl.cuh:213-226)."""
         import torch
+
+        if sharded:
+            nstart = None if nstart is None else self._replicated(nstart)
+            personalization = None if personalization is None else self._replicated(personalization)
 
         ids = torch.arange(self.first, self.last, device=self.engine.device).to(self.vertex_dtype)
         kw = dict(alpha=alpha, epsilon=epsilon,
@@ -456,7 +493,7 @@ class MGPagerank:
 
 
 def pagerank(resource_handle, graph_properties, src, dst, wgt, num_vertices, *, alpha=0.85,
-             tol=1.0e-5, max_iter=100, nstart=None, personalization=None,
+             tol=1.0e-5, max_iter=100, nstart=None, personalization=None, sharded=False,
              fail_on_nonconvergence=True, group=None):
     """cugraph.dask.pagerank-shaped convenience call (dask/link_analysis/pagerank.py:174-183):
     returns this rank's (vertices, pageranks[, converged])."""
@@ -464,7 +501,8 @@ def pagerank(resource_handle, graph_properties, src, dst, wgt, num_vertices, *, 
 
     drv = MGPagerank.from_edges(HipEngine(resource_handle, graph_properties), src, dst, wgt,
                                 num_vertices, group=group)
-    sess = drv.session(alpha=alpha, epsilon=tol, nstart=nstart, personalization=personalization)
+    sess = drv.session(alpha=alpha, epsilon=tol, nstart=nstart, personalization=personalization,
+                       sharded=sharded)
     drv.run_to_convergence(sess, max_iter)
     verts, vals, iters, conv = drv.result(sess, max_iter)
     if fail_on_nonconvergence:

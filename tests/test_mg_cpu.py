@@ -46,8 +46,18 @@ def _worker(rank, world, port, case, out_dir):
         if "want_regions" in case:
             assert (drv.regions is not None) == case["want_regions"]
         assert drv.graph.first == first and len(drv.out_w) == last - first
-        sess = drv.session(alpha=0.85, epsilon=case["eps"], nstart=case.get("nstart"),
-                           personalization=case.get("pers"))
+        nstart, pers = case.get("nstart"), case.get("pers")
+        if case.get("sharded"):
+            # every rank holds an arbitrary share of each list (one of them none of the
+            # personalization at all), not the pairs of the vertices it owns
+            share = lambda pairs, r: None if pairs is None else tuple(a[r::world][::-1].copy() for a in pairs)  # noqa: E731
+            nstart, pers = share(nstart, (rank + 1) % world), share(pers, rank)
+            if rank == world - 1 and pers is not None:
+                pers = tuple(np.concatenate([a[r::world] for r in (rank, 0)]) for a in case["pers"])
+            if rank == 0 and pers is not None:
+                pers = (pers[0][:0], pers[1][:0])
+        sess = drv.session(alpha=0.85, epsilon=case["eps"], nstart=nstart, personalization=pers,
+                           sharded=bool(case.get("sharded")))
         iters, stopped, _ = drv.run_to_convergence(sess, case["max_iter"], check_every=case["check"])
         full, it2, conv = drv.gathered_result(sess, case["max_iter"])
         verts, vals, _, _ = drv.result(sess, case["max_iter"])
@@ -111,14 +121,17 @@ def test_mg_matches_single_process_oracle(world, regions, want_regions, weighted
     assert abs(fulls[0].sum() - 1.0) < 1e-9
 
 
-def test_mg_personalization_nstart_and_nonconvergence(tmp_path):
+@pytest.mark.parametrize("sharded", [False, True])
+def test_mg_personalization_nstart_and_nonconvergence(sharded, tmp_path):
+    """sharded: the (vertex, value) lists arrive as per-rank shares in any order, as the reference's
+    MG entry takes them (mg_pagerank_test.c:67-94), instead of replicated on every rank"""
     rng = np.random.default_rng(0)
     nv = 1 << 9
     pers = (rng.permutation(nv)[:37].astype(np.int64), rng.random(37) + 0.1)  # un-normalised
     nstart = (rng.permutation(nv)[:300].astype(np.int64), rng.random(300))
     case = _rmat_case(9, True, pers=pers, nstart=nstart, max_iter=4, eps=1e-30, check=1, regions="1",
-                      want_regions=True)
-    fulls, metas = _run(2, case, tmp_path)
+                      want_regions=True, sharded=sharded)
+    fulls, metas = _run(3 if sharded else 2, case, tmp_path)
     o_pr, o_it, o_conv = _oracle(case)
     assert o_it == 4 and not o_conv
     for f, m in zip(fulls, metas):
