@@ -15,6 +15,47 @@ class _EdgeList:
         self.weights = weighted
 
 
+class _NumberMap:
+    """External vertices that are not one integer column -- strings, or several columns per vertex
+    -- against dense integer ids (reference: structure/number_map.py:28-110 NumberMap.SingleGPU:
+    to_internal_vertex_id / from_internal_vertex_id; :603-722 unrenumber and its column naming).
+    Host-side, with pandas: the distinct vertices in sorted order are the ids."""
+
+    def __init__(self, frames):
+        import pandas as pd
+
+        k = frames[0].shape[1]
+        self.col_names = [str(i) for i in range(k)]
+        parts = [f.set_axis(self.col_names, axis=1) for f in frames]
+        self.table = (pd.concat(parts, ignore_index=True).drop_duplicates()
+                      .sort_values(self.col_names, kind="stable").reset_index(drop=True))
+        self._index = self._key(self.table)
+        if len(self.table) >= 2**31 - 1:
+            raise NotImplementedError("2^31 or more vertices are not supported")
+
+    def _key(self, frame):
+        import pandas as pd
+
+        if frame.shape[1] != len(self.col_names):
+            raise ValueError(f"a vertex of this graph has {len(self.col_names)} column(s), got {frame.shape[1]}")
+        if len(self.col_names) == 1:
+            return pd.Index(frame.iloc[:, 0])
+        return pd.MultiIndex.from_frame(frame.set_axis(self.col_names, axis=1))
+
+    def to_internal(self, frame):
+        ids = self._index.get_indexer(self._key(frame))
+        if (ids < 0).any():
+            raise ValueError("vertex not found in the graph")
+        return ids.astype(np.int32)
+
+    def from_internal(self, ids, column_name):
+        """frame of the external vertices of `ids`: `column_name`, or `{i}_{column_name}` per column"""
+        out = self.table.iloc[np.asarray(ids, dtype=np.int64)].reset_index(drop=True)
+        if len(self.col_names) == 1:
+            return out.set_axis([column_name], axis=1)
+        return out.set_axis([f"{c}_{column_name}" for c in self.col_names], axis=1)
+
+
 class Graph:
     def __init__(self, m_graph=None, directed=False):
         if m_graph is not None:
@@ -27,6 +68,7 @@ class Graph:
         self._plc_graph = None
         self._resource_handle = None
         self._num_vertices = 0
+        self.renumber_map = None  # _NumberMap: string or multi-column vertices
 
     # ------------------------------------------------------------------ queries
     def is_directed(self):
@@ -61,9 +103,11 @@ class Graph:
             raise TypeError("pdf input is not a Pandas DataFrame")
         if self.edgelist is not None:
             raise RuntimeError("Graph already has values")
-        for col in (source, destination):
-            if isinstance(col, (list, tuple)):
-                raise NotImplementedError("multi-column vertices are outside the PageRank path")
+        s_cols = list(source) if isinstance(source, (list, tuple)) else [source]
+        d_cols = list(destination) if isinstance(destination, (list, tuple)) else [destination]
+        if len(s_cols) != len(d_cols) or not s_cols:
+            raise ValueError("source and destination must name the same number of columns")
+        for col in s_cols + d_cols:
             if col not in pdf.columns:
                 raise ValueError("source column names and/or destination column names not found in "
                                  "input. Recheck the source and destination parameters")
@@ -74,11 +118,22 @@ class Graph:
             wcol = wcol[0]
         if wcol is not None and wcol not in pdf.columns:
             raise ValueError("edge_attr column name not found in input. Recheck the edge_attr parameter")
-        df = pd.DataFrame({"src": pdf[source].to_numpy(), "dst": pdf[destination].to_numpy()})
+        if len(s_cols) > 1 or pdf[s_cols[0]].dtype.kind not in "iu" or pdf[d_cols[0]].dtype.kind not in "iu":
+            # number_map.py: vertices named by strings or by several columns get integer ids here;
+            # results and (vertex, value) frames are translated in cugraph.pagerank
+            frames = [pdf[s_cols], pdf[d_cols]]
+            if vertices is not None:
+                vf = vertices if isinstance(vertices, pd.DataFrame) else pd.DataFrame({"0": np.asarray(vertices)})
+                frames.append(vf)
+                vertices = None
+            self.renumber_map = _NumberMap(frames)
+            df = pd.DataFrame({"src": self.renumber_map.to_internal(pdf[s_cols]),
+                               "dst": self.renumber_map.to_internal(pdf[d_cols])})
+            vertices = np.arange(len(self.renumber_map.table), dtype=np.int32)
+        else:
+            df = pd.DataFrame({"src": pdf[s_cols[0]].to_numpy(), "dst": pdf[d_cols[0]].to_numpy()})
         if df["src"].dtype != df["dst"].dtype:
             raise ValueError("source and destination columns must have the same dtype")
-        if df["src"].dtype.kind not in "iu":
-            raise NotImplementedError("non-integer vertex ids are outside the PageRank path")
         if df["src"].dtype not in (np.int32, np.int64):
             df = df.astype({"src": np.int64, "dst": np.int64})
         if wcol is not None:

@@ -30,6 +30,8 @@ def ensure_valid_dtype(input_graph, input_df, input_df_name):
             )
             warnings.warn(warning_msg, UserWarning)
             input_df = input_df.astype({"values": edge_attr_dtype})
+    if input_graph.renumber_map is not None:
+        return input_df  # vertices are translated through the number map (_vertex_ids)
     vertex_dtype = input_graph.edgelist.edgelist_df.dtypes.iloc[0]
     input_df_vertex_dtype = input_df["vertex"].dtype
     if input_df_vertex_dtype != vertex_dtype:
@@ -76,6 +78,18 @@ def _dev(series):
     return torch.from_numpy(np.ascontiguousarray(series.to_numpy())).cuda()
 
 
+def _vertex_ids(G, input_df):
+    """device ids of a (vertex, value) frame's vertices.  Through the number map when the graph's
+    vertices are strings or several columns: then every column but the last names the vertex
+    (pagerank.py:33-40 renumber_vertices)."""
+    import torch
+
+    if G.renumber_map is None:
+        return _dev(input_df["vertex"])
+    cols = list(input_df.columns[:-1]) if len(G.renumber_map.col_names) > 1 else ["vertex"]
+    return torch.from_numpy(G.renumber_map.to_internal(input_df[cols])).cuda()
+
+
 def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=None, max_iter=100,
              tol=1.0e-5, nstart=None, weight=None, dangling=None, fail_on_nonconvergence=True):
     """Same arguments, defaults, warnings, exceptions and return shape as cugraph.pagerank;
@@ -109,7 +123,7 @@ def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=
     # reference's renumber_vertices / unrenumber round trips (pagerank.py:33-40, 299-300) vanish
     if nstart is not None:
         nstart = ensure_valid_dtype(G, nstart, "nstart")
-        initial_guess_vertices, initial_guess_values = _dev(nstart["vertex"]), _dev(nstart["values"])
+        initial_guess_vertices, initial_guess_values = _vertex_ids(G, nstart), _dev(nstart["values"])
     if precomputed_vertex_out_weight is not None:
         precomputed_vertex_out_weight = ensure_valid_dtype(G, precomputed_vertex_out_weight,
                                                            "precomputed_vertex_out_weight")
@@ -117,7 +131,7 @@ def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=
         want = np.float32 if G.edgelist.weights is False else G.edgelist.edgelist_df["weights"].dtype
         if sums.dtype != want:
             sums = sums.astype(want)
-        pre_vtx_o_wgt_vertices = _dev(precomputed_vertex_out_weight["vertex"])
+        pre_vtx_o_wgt_vertices = _vertex_ids(G, precomputed_vertex_out_weight)
         pre_vtx_o_wgt_sums = _dev(sums)
     try:
         if personalization is not None:
@@ -132,7 +146,7 @@ def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=
                 graph=G._plc_graph,
                 precomputed_vertex_out_weight_vertices=pre_vtx_o_wgt_vertices,
                 precomputed_vertex_out_weight_sums=pre_vtx_o_wgt_sums,
-                personalization_vertices=_dev(personalization["vertex"]),
+                personalization_vertices=_vertex_ids(G, personalization),
                 personalization_values=_dev(personalization["values"]),
                 initial_guess_vertices=initial_guess_vertices,
                 initial_guess_values=initial_guess_values,
@@ -162,6 +176,9 @@ def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=
     # PageRank may have transposed the graph in place (pagerank.cpp:105-110)
     df = pd.DataFrame({"vertex": result_tuple[0].cpu().numpy(),
                        "pagerank": result_tuple[1].cpu().numpy()})
+    if G.renumber_map is not None:  # G.unrenumber(df, "vertex"), number_map.py:659-668 for the names
+        ext = G.renumber_map.from_internal(df["vertex"].to_numpy(), "vertex")
+        df = pd.concat([ext, df[["pagerank"]]], axis=1)
     out = dict(zip(df["vertex"].tolist(), df["pagerank"].tolist())) if isNx else df
     if fail_on_nonconvergence:
         return out

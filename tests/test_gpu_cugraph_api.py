@@ -224,3 +224,55 @@ def test_drop_self_loops_and_multi_edges(name, renumber, symmetric):
     v, r = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-7, 500, False)
     got_pr = dict(zip(v.cpu().numpy().tolist(), r.cpu().numpy().tolist()))
     assert max(abs(got_pr[n] - want[n]) for n in want) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["strings", "two_columns"])
+@pytest.mark.parametrize("renumber", [True, False])
+def test_string_and_multi_column_vertices(kind, renumber):
+    """Vertices named by strings or by several columns (number_map.py; the reference's
+    test_pagerank_multi_column, test_pagerank.py:300-366): ranks equal the integer-id run's, the
+    result names its vertices the way unrenumber does (`vertex`, or `0_vertex`, `1_vertex`), and
+    personalization / nstart frames use the same naming with the value column last."""
+    from cugraph_amd import cugraph
+
+    pdf = _karate_frame()
+    base = cugraph.pagerank(_directed_graph(), max_iter=500, tol=1e-7)
+    want = dict(zip(base["vertex"].tolist(), base["pagerank"].tolist()))
+    pers_int = pd.DataFrame({"vertex": np.array([17, 26], np.int32), "values": np.array([0.5, 0.75], np.float32)})
+    base_p = cugraph.pagerank(_directed_graph(), personalization=pers_int, max_iter=500, tol=1e-7)
+    want_p = dict(zip(base_p["vertex"].tolist(), base_p["pagerank"].tolist()))
+    G = cugraph.Graph(directed=True)
+    if kind == "strings":
+        name = lambda v: f"member-{v:02d}"  # noqa: E731
+        frame = pd.DataFrame({"a": [name(v) for v in pdf["src"]], "b": [name(v) for v in pdf["dst"]],
+                              "w": pdf["weights"]})
+        G.from_cudf_edgelist(frame, source="a", destination="b", edge_attr="w", store_transposed=True,
+                             renumber=renumber)
+        pers = pd.DataFrame({"vertex": [name(17), name(26)], "values": np.array([0.5, 0.75], np.float32)})
+        nstart = pd.DataFrame({"vertex": [name(v) for v in range(34)], "values": np.full(34, 1 / 34, np.float32)})
+        key = lambda df: [int(v[-2:]) for v in df["vertex"]]  # noqa: E731
+        cols = ["vertex", "pagerank"]
+        bad = pd.DataFrame({"vertex": ["nobody"], "values": np.array([1.0], np.float32)})
+    else:
+        split = lambda s: (s // 10 + 1000, s % 10)  # noqa: E731
+        frame = pd.DataFrame({"s0": split(pdf["src"])[0], "s1": split(pdf["src"])[1],
+                              "d0": split(pdf["dst"])[0], "d1": split(pdf["dst"])[1], "w": pdf["weights"]})
+        G.from_cudf_edgelist(frame, source=["s0", "s1"], destination=["d0", "d1"], edge_attr="w",
+                             store_transposed=True, renumber=renumber)
+        pers = pd.DataFrame({"0_vertex": [1001, 1002], "1_vertex": [7, 6], "values": np.array([0.5, 0.75], np.float32)})
+        ids = np.arange(34)
+        nstart = pd.DataFrame({"0_vertex": ids // 10 + 1000, "1_vertex": ids % 10,
+                               "values": np.full(34, 1 / 34, np.float32)})
+        key = lambda df: ((df["0_vertex"] - 1000) * 10 + df["1_vertex"]).tolist()  # noqa: E731
+        cols = ["0_vertex", "1_vertex", "pagerank"]
+        bad = pd.DataFrame({"0_vertex": [1001], "1_vertex": [99], "values": np.array([1.0], np.float32)})
+    assert G.number_of_vertices() == 34
+    df = cugraph.pagerank(G, max_iter=500, tol=1e-7)
+    assert list(df.columns) == cols and len(df) == 34
+    got = dict(zip(key(df), df["pagerank"].tolist()))
+    assert set(got) == set(want) and max(abs(got[v] - want[v]) for v in want) < 1e-7
+    df = cugraph.pagerank(G, personalization=pers, nstart=nstart, max_iter=500, tol=1e-7)
+    got = dict(zip(key(df), df["pagerank"].tolist()))
+    assert max(abs(got[v] - want_p[v]) for v in want_p) < 1e-6
+    with pytest.raises(ValueError, match="vertex not found"):
+        cugraph.pagerank(G, personalization=bad)
