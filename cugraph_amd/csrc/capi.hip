@@ -133,6 +133,7 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
   g->num_edges        = ne;
 
   int64_t n_major, n_minor, major_shift = 0;
+  DevBuf major_counts;  // edges per major, when the renumbering has counted them already
   if (num_global >= 0) {  // local part of a 1D destination partition
     CGA_EXPECTS(store_transposed, CUGRAPH_INVALID_INPUT, "a partitioned graph is always stored transposed");
     CGA_EXPECTS(0 <= vertex_first && vertex_first <= vertex_last && vertex_last <= num_global,
@@ -164,7 +165,7 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
   } else if (renumber) {
     // create_graph_from_edgelist_impl.cuh:925-941: ids become 0..V-1 by descending major degree
     renumber_edgelist(h, *g, vertices, src, dst, store_transposed, s32.as<int32_t>(),
-                      d32.as<int32_t>());
+                      d32.as<int32_t>(), &major_counts);
     n_major = n_minor = g->num_vertices;
     // create_graph_from_edgelist_impl.cuh:84-89, for id spans expensive_check_vertices cannot table
     CGA_EXPECTS(!(do_expensive_check && vertices) ||
@@ -197,7 +198,8 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
   }
   CompressedOut out = compress_coo(stream, n_major, n_minor, ne, majors, minors,
                                    weights ? weights->data : nullptr,
-                                   weights ? dtype_size(weights->type) : 0);
+                                   weights ? dtype_size(weights->type) : 0,
+                                   major_counts.p ? major_counts.as<unsigned int>() : nullptr);
   g->off64   = out.off64;
   g->offsets = out.offsets.detach();
   g->indices = static_cast<int32_t*>(out.indices.detach());

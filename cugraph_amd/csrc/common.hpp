@@ -248,7 +248,8 @@ struct CompressedOut {
 };
 
 // COO (majors, minors int32, already validated to lie in [0, n_major) x [0, n_minor)) -> compressed,
-// minors ascending inside each major, ties in input order.
+// minors ascending inside each major, ties in input order.  major_counts: the number of edges of
+// every major, when the caller has it (saves the histogram pass).
 CompressedOut compress_coo(hipStream_t stream,
                            int64_t n_major,
                            int64_t n_minor,
@@ -256,7 +257,8 @@ CompressedOut compress_coo(hipStream_t stream,
                            int32_t const* majors,
                            int32_t const* minors,
                            void const* weights,
-                           size_t weight_size);
+                           size_t weight_size,
+                           unsigned int const* major_counts = nullptr);
 
 CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_minor,
                                 int64_t n_edges, int32_t const* majors, int32_t const* minors);
@@ -278,8 +280,10 @@ void transpose_graph(Handle const& h, Graph& g);
 void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf& order, DevBuf& rank);
 void relabel_ids(hipStream_t stream, int32_t* ids, int64_t n, int32_t const* table);
 Graph* degree_sorted_copy(Handle const& h, Graph const& g);
+// major_counts_out: if given, receives the number of edges of every major in the NEW numbering
 void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
-                       ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32);
+                       ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32,
+                       DevBuf* major_counts_out = nullptr);
 
 void partition_degree_order(hipStream_t stream, ArrayView const& dst, int64_t first, int64_t count,
                             int32_t* order_out, int32_t* rank_out);

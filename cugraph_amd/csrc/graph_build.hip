@@ -90,6 +90,59 @@ __global__ void hist_kernel(int32_t const* __restrict__ keys, int64_t n,
     atomicAdd(&counts[keys[i]], 1u);
 }
 
+// Long columns (the pull plan's (tile, slice, window) units: each takes thousands to millions of
+// keys): global atomics would all land on the same few counters.  Every workgroup takes a
+// contiguous span of the keys; when the majors of its span fit a window of kLdsMajors values
+// (they do when the input is grouped, as the plan's unit labels in row order are) it counts them
+// in LDS and touches each global counter once, else it falls back to global atomics.
+constexpr int kLdsMajors = 32768;  // 128 of the 160 KiB of LDS
+
+// smallest major of the workgroup's span and whether all of them fit the LDS window above it
+__device__ inline bool span_window(int32_t const* __restrict__ keys, int64_t beg, int64_t end, int32_t* first)
+{
+  __shared__ int s_min, s_max;
+  if (threadIdx.x == 0) { s_min = 0x7fffffff; s_max = -1; }
+  __syncthreads();
+  int lo = 0x7fffffff, hi = -1;
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    int k = keys[i];
+    lo    = k < lo ? k : lo;
+    hi    = k > hi ? k : hi;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&s_min, lo);
+    atomicMax(&s_max, hi);
+  }
+  __syncthreads();
+  *first = s_min;
+  return s_max >= s_min && s_max - s_min < kLdsMajors;
+}
+
+__global__ __launch_bounds__(1024) void hist_lds_kernel(int32_t const* __restrict__ keys, int64_t n,
+                                                        unsigned int* __restrict__ counts)
+{
+  extern __shared__ unsigned int lds_count[];
+  int64_t const span = (n + gridDim.x - 1) / gridDim.x;
+  int64_t const beg = blockIdx.x * span, end = beg + span < n ? beg + span : n;
+  if (beg >= end) return;
+  int32_t first;
+  if (!span_window(keys, beg, end, &first)) {
+    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&counts[keys[i]], 1u);
+    return;
+  }
+  for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) lds_count[k] = 0u;
+  __syncthreads();
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&lds_count[keys[i] - first], 1u);
+  __syncthreads();
+  for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x)
+    if (lds_count[k]) atomicAdd(&counts[first + k], lds_count[k]);
+}
+
 // ------------------------------------------------------------------ 2. exclusive scan
 constexpr int kScanItems = 16;                     // per thread
 constexpr int kScanTile  = kThreads * kScanItems;  // 4096 per block
@@ -202,6 +255,47 @@ __global__ void scatter_kernel(int32_t const* __restrict__ majors,
     }
     keys[offsets[m] + pos] = k;
   }
+}
+
+// scatter for long columns (see hist_lds_kernel): a workgroup counts its span in LDS, reserves one
+// run per major it met with a single global atomic, then hands out the positions of the run with
+// LDS atomics.  32-bit offsets only (the positions live in LDS words).
+template <typename KeyT>
+__global__ __launch_bounds__(1024) void scatter_lds_kernel(int32_t const* __restrict__ majors,
+                                                           int32_t const* __restrict__ minors, int64_t n,
+                                                           int32_t const* __restrict__ offsets,
+                                                           unsigned int* __restrict__ cursor,
+                                                           KeyT* __restrict__ keys)
+{
+  extern __shared__ unsigned int lds_pos[];
+  int64_t const span = (n + gridDim.x - 1) / gridDim.x;
+  int64_t const beg = blockIdx.x * span, end = beg + span < n ? beg + span : n;
+  if (beg >= end) return;
+  auto key_of = [&](int64_t e) {
+    if constexpr (sizeof(KeyT) == 8)
+      return (static_cast<KeyT>(static_cast<uint32_t>(minors[e])) << 32) | static_cast<KeyT>(static_cast<uint32_t>(e));
+    else
+      return static_cast<KeyT>(minors[e]);
+  };
+  int32_t first;
+  if (!span_window(majors, beg, end, &first)) {
+    for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
+      int32_t const m = majors[e];
+      keys[static_cast<unsigned int>(offsets[m]) + atomicAdd(&cursor[m], 1u)] = key_of(e);
+    }
+    return;
+  }
+  for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) lds_pos[k] = 0u;
+  __syncthreads();
+  for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) atomicAdd(&lds_pos[majors[e] - first], 1u);
+  __syncthreads();
+  for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) {
+    unsigned int const c = lds_pos[k];
+    if (c) lds_pos[k] = static_cast<unsigned int>(offsets[first + k]) + atomicAdd(&cursor[first + k], c);
+  }
+  __syncthreads();
+  for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x)
+    keys[atomicAdd(&lds_pos[majors[e] - first], 1u)] = key_of(e);
 }
 
 // ------------------------------------------------------------------ 4. per-column ordering
@@ -489,9 +583,15 @@ void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t 
 template <typename OffT>
 CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                             int32_t const* majors, int32_t const* minors, void const* weights,
-                            size_t weight_size, bool want_perm = false)
+                            size_t weight_size, bool want_perm = false,
+                            unsigned int const* major_counts = nullptr)
 {
   CompressedOut out;
+  // long columns (512 edges or more on average): LDS-privatised histogram and scatter (hist_lds_kernel)
+  bool const few_majors = sizeof(OffT) == 4 && n_edges >= (int64_t{1} << 16) && n_edges / 512 >= n_major &&
+                          std::getenv("CUGRAPH_AMD_BUILD_NO_LDS") == nullptr;
+  size_t const lds_bytes = static_cast<size_t>(kLdsMajors) * sizeof(unsigned int);
+  int const lds_grid     = 1024;
   out.off64 = sizeof(OffT) == 8;
   out.offsets.alloc(static_cast<size_t>(n_major + 1) * sizeof(OffT));
   // +4 elements: the SpMV reads 16-byte aligned vectors and may touch up to 3 elements past the end
@@ -504,10 +604,41 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
   }
 
   DevBuf counts(static_cast<size_t>(n_major > 0 ? n_major : 1) * sizeof(unsigned int));
-  CGA_HIP(hipMemsetAsync(counts.p, 0, counts.bytes, stream));
-  if (n_edges > 0)
-    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n_edges)), dim3(kThreads), 0, stream, majors,
-                       n_edges, counts.as<unsigned int>());
+  if (major_counts && n_major > 0) {
+    // the caller already counted the edges of every major (the renumbering's degrees)
+    CGA_HIP(hipMemcpyAsync(counts.p, major_counts, static_cast<size_t>(n_major) * sizeof(unsigned int),
+                           hipMemcpyDeviceToDevice, stream));
+  } else {
+    CGA_HIP(hipMemsetAsync(counts.p, 0, counts.bytes, stream));
+    if (n_edges > 0 && few_majors) {
+      CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(hist_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(kLdsMajors * sizeof(unsigned int))));
+      hipLaunchKernelGGL(hist_lds_kernel, dim3(lds_grid), dim3(1024), lds_bytes, stream, majors, n_edges,
+                         counts.as<unsigned int>());
+    } else if (n_edges > 0) {
+      hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n_edges)), dim3(kThreads), 0, stream, majors,
+                         n_edges, counts.as<unsigned int>());
+    }
+  }
+  // scatter of (major, minor[, position]) into the columns: keys of type KeyT
+  auto scatter = [&](auto* keys) {
+    using KeyT = std::remove_pointer_t<decltype(keys)>;
+    if constexpr (sizeof(OffT) == 4) {
+      if (few_majors) {
+        auto kern = scatter_lds_kernel<KeyT>;
+        CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(kLdsMajors * sizeof(unsigned int))));
+        hipLaunchKernelGGL(kern, dim3(lds_grid), dim3(1024), lds_bytes, stream, majors, minors, n_edges,
+                           out.offsets.template as<int32_t>(), counts.as<unsigned int>(), keys);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((scatter_kernel<OffT, KeyT>), dim3(grid_for(n_edges)), dim3(kThreads), 0, stream,
+                       majors, minors, n_edges, out.offsets.template as<OffT>(), counts.as<unsigned int>(),
+                       keys);
+  };
 
   int64_t n_tiles = (n_major + kScanTile - 1) / kScanTile;
   if (n_tiles < 1) n_tiles = 1;
@@ -526,9 +657,7 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
       CGA_EXPECTS(n_edges <= 0xffffffffLL, CUGRAPH_NOT_IMPLEMENTED, "2^32 or more edges");
       out.perm.alloc(static_cast<size_t>(n_edges + 4) * sizeof(uint32_t));
       DevBuf keys(static_cast<size_t>(n_edges) * sizeof(unsigned long long));
-      hipLaunchKernelGGL((scatter_kernel<OffT, unsigned long long>), dim3(grid_for(n_edges)),
-                         dim3(kThreads), 0, stream, majors, minors, n_edges, out.offsets.as<OffT>(),
-                         counts.as<unsigned int>(), keys.as<unsigned long long>());
+      scatter(keys.as<unsigned long long>());
       order_columns<OffT, unsigned long long>(stream, out.offsets.as<OffT>(),
                                               keys.as<unsigned long long>(), n_major, n_minor,
                                               n_edges);
@@ -541,9 +670,7 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
       CGA_EXPECTS(n_edges <= 0xffffffffLL, CUGRAPH_NOT_IMPLEMENTED,
                   "weighted graphs with 2^32 or more edges per GPU are not supported");
       DevBuf keys(static_cast<size_t>(n_edges) * sizeof(unsigned long long));
-      hipLaunchKernelGGL((scatter_kernel<OffT, unsigned long long>), dim3(grid_for(n_edges)),
-                         dim3(kThreads), 0, stream, majors, minors, n_edges, out.offsets.as<OffT>(),
-                         counts.as<unsigned int>(), keys.as<unsigned long long>());
+      scatter(keys.as<unsigned long long>());
       order_columns<OffT, unsigned long long>(stream, out.offsets.as<OffT>(),
                                               keys.as<unsigned long long>(), n_major, n_minor,
                                               n_edges);
@@ -560,9 +687,7 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
       CGA_HIP(hipGetLastError());
       CGA_HIP(hipStreamSynchronize(stream));
     } else {
-      hipLaunchKernelGGL((scatter_kernel<OffT, uint32_t>), dim3(grid_for(n_edges)), dim3(kThreads),
-                         0, stream, majors, minors, n_edges, out.offsets.as<OffT>(),
-                         counts.as<unsigned int>(), out.indices.as<uint32_t>());
+      scatter(out.indices.as<uint32_t>());
       order_columns<OffT, uint32_t>(stream, out.offsets.as<OffT>(), out.indices.as<uint32_t>(),
                                     n_major, n_minor, n_edges);
     }
@@ -576,14 +701,14 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
 
 CompressedOut compress_coo(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                            int32_t const* majors, int32_t const* minors, void const* weights,
-                           size_t weight_size)
+                           size_t weight_size, unsigned int const* major_counts)
 {
   // same switch as the reference's edge_t choice (cpp/src/c_api/graph_sg.cpp:568-572)
   if (n_edges < 0x7fffffffLL)
     return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
-                                  weight_size);
+                                  weight_size, false, major_counts);
   return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
-                                weight_size);
+                                weight_size, false, major_counts);
 }
 
 // exclusive scan of 32-bit counts into 64-bit positions, out[n] = total (stream compaction helper)

@@ -77,6 +77,11 @@ __global__ void bit_split_kernel(unsigned int const* keys_in, int32_t const* val
   }
 }
 
+__global__ void gather_u32_kernel(unsigned int const* in, int32_t const* order, int64_t n, unsigned int* out)
+{
+  GRID_STRIDE(i, n) out[i] = in[order[i]];
+}
+
 __global__ void invert_kernel(int32_t const* order, int64_t n, int32_t* rank)
 {
   GRID_STRIDE(i, n) rank[order[i]] = (int32_t)i;
@@ -480,7 +485,7 @@ namespace {
 // binary search -- the same labels the table path gives, so everything after it is shared.
 void renumber_sparse_ids(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
                          ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32,
-                         long long lo, unsigned long long span)
+                         long long lo, unsigned long long span, DevBuf* major_counts_out)
 {
   hipStream_t stream = h.stream;
   int64_t const ne   = static_cast<int64_t>(src->size);
@@ -591,6 +596,11 @@ void renumber_sparse_ids(Handle const& h, Graph& g, ArrayView const* vertices, A
   degree_order_sources_first(stream, deg.as<unsigned int>(), majors_are_dst ? src32 : dst32, ne, nv, order, rank);
   relabel_ids(stream, src32, ne, rank.as<int32_t>());
   relabel_ids(stream, dst32, ne, rank.as<int32_t>());
+  if (major_counts_out && nv > 0) {  // the degrees in the new order: the build's histogram, for free
+    major_counts_out->alloc(static_cast<size_t>(nv) * 4);
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, deg.as<unsigned int>(),
+                       order.as<int32_t>(), nv, major_counts_out->as<unsigned int>());
+  }
   // ---- number_map (new -> external); external -> new = search of `sorted`, then rank
   DevBuf nmap(nn * dtype_size(g.vertex_type));
   if (nv > 0) {
@@ -615,7 +625,8 @@ void renumber_sparse_ids(Handle const& h, Graph& g, ArrayView const* vertices, A
 }  // namespace
 
 void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, ArrayView const* src,
-                       ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32)
+                       ArrayView const* dst, bool majors_are_dst, int32_t* src32, int32_t* dst32,
+                       DevBuf* major_counts_out)
 {
   hipStream_t stream = h.stream;
   int64_t ne         = static_cast<int64_t>(src->size);
@@ -648,7 +659,7 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
                                             static_cast<unsigned long long>(h_mm[0]);
   bool const sparse = span >= 0x7ffffffeull || (!empty && std::getenv("CUGRAPH_AMD_RENUMBER_SPARSE") != nullptr);
   if (sparse) {
-    renumber_sparse_ids(h, g, vertices, src, dst, majors_are_dst, src32, dst32, lo, span);
+    renumber_sparse_ids(h, g, vertices, src, dst, majors_are_dst, src32, dst32, lo, span, major_counts_out);
     return;
   }
   long long range = empty ? 0 : static_cast<long long>(span) + 1;
@@ -708,6 +719,11 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
   degree_order_sources_first(stream, deg.as<unsigned int>(), majors_are_dst ? src32 : dst32, ne, nv, order, rank);
   relabel_ids(stream, src32, ne, rank.as<int32_t>());
   relabel_ids(stream, dst32, ne, rank.as<int32_t>());
+  if (major_counts_out && nv > 0) {  // the degrees in the new order: the build's histogram, for free
+    major_counts_out->alloc(static_cast<size_t>(nv) * 4);
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, deg.as<unsigned int>(),
+                       order.as<int32_t>(), nv, major_counts_out->as<unsigned int>());
+  }
   // ---- number_map (new -> external) and the external -> new lookup
   DevBuf nmap(static_cast<size_t>(nv > 0 ? nv : 1) * dtype_size(g.vertex_type));
   DevBuf lookup(rr * 4);
