@@ -260,8 +260,11 @@ CompressedOut compress_coo(hipStream_t stream,
                            size_t weight_size,
                            unsigned int const* major_counts = nullptr);
 
+// ties_in_input_order = false: equal minors of a LONG column may come out in any order (saves
+// half of the radix passes; the permutation stays valid)
 CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_minor,
-                                int64_t n_edges, int32_t const* majors, int32_t const* minors);
+                                int64_t n_edges, int32_t const* majors, int32_t const* minors,
+                                bool ties_in_input_order = true);
 
 // offsets -> one major id per edge (the inverse of the histogram+scan)
 void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,

@@ -533,7 +533,7 @@ inline int bit_width_u64(uint64_t v)
 
 template <typename OffT, typename KeyT>
 void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t n_major,
-                   int64_t n_minor, int64_t n_edges)
+                   int64_t n_minor, int64_t n_edges, bool ties_in_input_order = true)
 {
   if (n_edges < 2) return;
   hipLaunchKernelGGL((sort_small_kernel<OffT, KeyT, 16>), dim3(grid_for(n_major * 16)), dim3(kThreads),
@@ -562,7 +562,8 @@ void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t 
     if constexpr (sizeof(KeyT) == 8) {
       int be = bit_width_u64(static_cast<uint64_t>(n_edges - 1));
       int bv = bit_width_u64(static_cast<uint64_t>(n_minor > 0 ? n_minor - 1 : 0));
-      for (int s = 0; s < be; s += 8) passes.shift[passes.n++] = s;
+      // (the low word is the input position: it only decides the order of equal minors)
+      for (int s = 0; s < be && ties_in_input_order; s += 8) passes.shift[passes.n++] = s;
       for (int s = 0; s < bv; s += 8) passes.shift[passes.n++] = 32 + s;
     } else {
       int bv = bit_width_u64(static_cast<uint64_t>(n_minor > 0 ? n_minor - 1 : 0));
@@ -584,7 +585,7 @@ template <typename OffT>
 CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                             int32_t const* majors, int32_t const* minors, void const* weights,
                             size_t weight_size, bool want_perm = false,
-                            unsigned int const* major_counts = nullptr)
+                            unsigned int const* major_counts = nullptr, bool ties_in_input_order = true)
 {
   CompressedOut out;
   // long columns (512 edges or more on average): LDS-privatised histogram and scatter (hist_lds_kernel)
@@ -660,7 +661,7 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
       scatter(keys.as<unsigned long long>());
       order_columns<OffT, unsigned long long>(stream, out.offsets.as<OffT>(),
                                               keys.as<unsigned long long>(), n_major, n_minor,
-                                              n_edges);
+                                              n_edges, ties_in_input_order);
       hipLaunchKernelGGL(unpack_perm_kernel, dim3(grid_for(n_edges)), dim3(kThreads), 0, stream,
                          keys.as<unsigned long long>(), n_edges, out.indices.as<int32_t>(),
                          out.perm.as<uint32_t>());
@@ -773,11 +774,14 @@ Graph::~Graph()
 
 // as compress_coo, without weights, plus perm[k] = input position of the edge stored at k
 CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_minor,
-                                int64_t n_edges, int32_t const* majors, int32_t const* minors)
+                                int64_t n_edges, int32_t const* majors, int32_t const* minors,
+                                bool ties_in_input_order)
 {
   if (n_edges < 0x7fffffffLL)
-    return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true);
-  return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true);
+    return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true,
+                                  nullptr, ties_in_input_order);
+  return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true,
+                                nullptr, ties_in_input_order);
 }
 
 void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,

@@ -1454,8 +1454,9 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
                      offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(), slice_shift,
                      n_win, row_bits, unit.as<int32_t>(), row_of_edge.as<int32_t>());
   CGA_HIP(hipGetLastError());
+  // (entries of one source inside a unit go to different rows: their order does not matter)
   CompressedOut c = compress_coo_perm(stream, n_units, g.minor_space(), ne, unit.as<int32_t>(),
-                                      g.indices + e0);
+                                      g.indices + e0, false);
   unit.release();
   plan.xs_ent.alloc(static_cast<size_t>(ne + 4) * sizeof(uint32_t));
   CGA_HIP(hipMemsetAsync(plan.xs_ent.p, 0, plan.xs_ent.bytes, stream));

@@ -122,6 +122,61 @@ __global__ void to_dense_kernel(IdT const* ids, int64_t n, long long lo, unsigne
   }
 }
 
+// the table path of renumber_edgelist: tally[id - lo] = edges whose major is id (low 31 bits),
+// top bit: id occurs as a minor
+constexpr unsigned int kMinorBit = 0x80000000u;
+
+template <typename IdT>
+__global__ void tally_majors_kernel(IdT const* __restrict__ ids, int64_t n, long long lo, unsigned int* tally)
+{
+  GRID_STRIDE(i, n) atomicAdd(&tally[(long long)ids[i] - lo], 1u);
+}
+
+template <typename IdT>
+__global__ void tally_minors_kernel(IdT const* __restrict__ ids, int64_t n, long long lo, unsigned int* tally)
+{
+  GRID_STRIDE(i, n)
+  {
+    unsigned int* t = &tally[(long long)ids[i] - lo];
+    if (!(__atomic_load_n(t, __ATOMIC_RELAXED) & kMinorBit)) atomicOr(t, kMinorBit);
+  }
+}
+
+__global__ void flags_of_tally_kernel(unsigned int const* __restrict__ tally, int64_t n, unsigned int* flags)
+{
+  GRID_STRIDE(k, n) flags[k] = tally[k] ? 1u : 0u;
+}
+
+__global__ void count_unlisted_kernel(unsigned int const* __restrict__ tally, unsigned int const* __restrict__ flags,
+                                      int64_t n, unsigned int* n_unknown)
+{
+  unsigned int c = 0;
+  GRID_STRIDE(k, n) c += (tally[k] && !flags[k]) ? 1u : 0u;
+  if (c) atomicAdd(n_unknown, c);
+}
+
+__global__ void compact_tally_kernel(unsigned int const* __restrict__ tally, unsigned int const* __restrict__ flags,
+                                     int64_t const* __restrict__ pos, int64_t n, unsigned int* __restrict__ deg,
+                                     unsigned int* __restrict__ is_minor)
+{
+  GRID_STRIDE(k, n)
+  {
+    if (flags[k]) {
+      unsigned int const t = tally[k];
+      deg[pos[k]]          = t & ~kMinorBit;
+      is_minor[pos[k]]     = t >> 31;
+    }
+  }
+}
+
+// endpoint -> new id through the external -> new table (every endpoint is a known vertex by now)
+template <typename IdT>
+__global__ void lookup_ids_kernel(IdT const* __restrict__ ids, int64_t n, long long lo,
+                                  int32_t const* __restrict__ lookup, int32_t* __restrict__ out)
+{
+  GRID_STRIDE(i, n) out[i] = lookup[(long long)ids[i] - lo];
+}
+
 template <typename IdT>
 __global__ void number_map_kernel(int64_t range, long long lo, unsigned int const* flags,
                                   int64_t const* pos, int32_t const* rank, IdT* number_map,
@@ -288,6 +343,18 @@ __global__ void degree_keys_kernel(unsigned int const* __restrict__ deg, unsigne
 // the vertices WITHOUT major edges, where those that still occur as a minor come first.  What is
 // left at the very end are the vertices no edge touches; PageRank never has to visit them
 // (pagerank.hip: dead rows).
+// the same order from "occurs as a minor" flags the caller already has
+void degree_order_marked(hipStream_t stream, unsigned int const* deg, unsigned int const* is_minor, int64_t n,
+                         DevBuf& order, DevBuf& rank)
+{
+  size_t nn = static_cast<size_t>(n > 0 ? n : 1);
+  DevBuf keys(nn * 4);
+  if (n > 0)
+    hipLaunchKernelGGL(degree_keys_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, deg, is_minor, n,
+                       keys.as<unsigned int>());
+  degree_order(stream, keys.as<unsigned int>(), n, order, rank);
+}
+
 void degree_order_sources_first(hipStream_t stream, unsigned int const* deg, int32_t const* minors,
                                 int64_t n_edges, int64_t n, DevBuf& order, DevBuf& rank)
 {
@@ -664,68 +731,72 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
   }
   long long range = empty ? 0 : static_cast<long long>(span) + 1;
   size_t rr = static_cast<size_t>(range > 0 ? range : 1);
-  // ---- vertex set: the given list, or every endpoint
-  DevBuf flags(rr * 4), pos((rr + 1) * 8);
-  CGA_HIP(hipMemsetAsync(flags.p, 0, rr * 4, stream));
-  auto mark = [&](ArrayView const* a) {
-    if (!a || a->size == 0) return;
-    int64_t n = static_cast<int64_t>(a->size);
-    if (wide)
-      hipLaunchKernelGGL((mark_ids_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
-                         static_cast<int64_t const*>(a->data), n, lo, flags.as<unsigned int>());
-    else
-      hipLaunchKernelGGL((mark_ids_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
-                         static_cast<int32_t const*>(a->data), n, lo, flags.as<unsigned int>());
-  };
-  if (vertices) {
-    mark(vertices);
-  } else {
-    mark(src);
-    mark(dst);
+  // ---- one table over [lo, lo + range): edges per major and "occurs as a minor" (top bit) of
+  // every external id, counted on the ids as they came in
+  DevBuf tally(rr * 4), flags(rr * 4), pos((rr + 1) * 8);
+  CGA_HIP(hipMemsetAsync(tally.p, 0, rr * 4, stream));
+  ArrayView const* major_ids = majors_are_dst ? dst : src;
+  ArrayView const* minor_ids = majors_are_dst ? src : dst;
+  if (ne > 0) {
+    if (wide) {
+      hipLaunchKernelGGL((tally_majors_kernel<int64_t>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(major_ids->data), ne, lo, tally.as<unsigned int>());
+      hipLaunchKernelGGL((tally_minors_kernel<int64_t>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(minor_ids->data), ne, lo, tally.as<unsigned int>());
+    } else {
+      hipLaunchKernelGGL((tally_majors_kernel<int32_t>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(major_ids->data), ne, lo, tally.as<unsigned int>());
+      hipLaunchKernelGGL((tally_minors_kernel<int32_t>), dim3(grid_for(ne)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(minor_ids->data), ne, lo, tally.as<unsigned int>());
+    }
   }
-  exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), range, pos.as<int64_t>());
-  int64_t nv = 0;
-  CGA_HIP(hipMemcpyAsync(&nv, pos.as<int64_t>() + range, 8, hipMemcpyDeviceToHost, stream));
-  CGA_HIP(hipStreamSynchronize(stream));
-  // ---- endpoints -> dense (ascending-id) labels
+  // ---- vertex set: the given list, or every id an edge mentions
   DevBuf unknown(4);
   CGA_HIP(hipMemsetAsync(unknown.p, 0, 4, stream));
-  auto densify = [&](ArrayView const* a, int32_t* out) {
-    if (a->size == 0) return;
-    int64_t n = static_cast<int64_t>(a->size);
-    if (wide)
-      hipLaunchKernelGGL((to_dense_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
-                         static_cast<int64_t const*>(a->data), n, lo, flags.as<unsigned int>(),
-                         pos.as<int64_t>(), out, unknown.as<unsigned int>());
-    else
-      hipLaunchKernelGGL((to_dense_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
-                         static_cast<int32_t const*>(a->data), n, lo, flags.as<unsigned int>(),
-                         pos.as<int64_t>(), out, unknown.as<unsigned int>());
-  };
-  densify(src, src32);
-  densify(dst, dst32);
+  if (vertices) {
+    CGA_HIP(hipMemsetAsync(flags.p, 0, rr * 4, stream));
+    if (vertices->size > 0) {
+      int64_t n = static_cast<int64_t>(vertices->size);
+      if (wide)
+        hipLaunchKernelGGL((mark_ids_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                           static_cast<int64_t const*>(vertices->data), n, lo, flags.as<unsigned int>());
+      else
+        hipLaunchKernelGGL((mark_ids_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                           static_cast<int32_t const*>(vertices->data), n, lo, flags.as<unsigned int>());
+    }
+    if (range > 0)  // ids the edges mention but the list does not hold
+      hipLaunchKernelGGL(count_unlisted_kernel, dim3(grid_for(range, 1024)), dim3(kThreads), 0, stream,
+                         tally.as<unsigned int>(), flags.as<unsigned int>(), static_cast<int64_t>(range),
+                         unknown.as<unsigned int>());
+  } else if (range > 0) {
+    hipLaunchKernelGGL(flags_of_tally_kernel, dim3(grid_for(range)), dim3(kThreads), 0, stream,
+                       tally.as<unsigned int>(), static_cast<int64_t>(range), flags.as<unsigned int>());
+  }
+  exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), range, pos.as<int64_t>());
+  int64_t nv             = 0;
   unsigned int h_unknown = 0;
+  CGA_HIP(hipMemcpyAsync(&nv, pos.as<int64_t>() + range, 8, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipMemcpyAsync(&h_unknown, unknown.p, 4, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
   CGA_EXPECTS(h_unknown == 0, CUGRAPH_INVALID_INPUT,
               "Invalid input arguments: edge endpoints missing from the vertex list.");
-  // ---- major degrees, order, relabel
-  DevBuf deg(static_cast<size_t>(nv > 0 ? nv : 1) * 4);
-  CGA_HIP(hipMemsetAsync(deg.p, 0, deg.bytes, stream));
-  if (ne > 0)
-    hipLaunchKernelGGL(hist_u32_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream,
-                       majors_are_dst ? dst32 : src32, ne, deg.as<unsigned int>());
+  // ---- degrees and minor marks of the dense (ascending-id) labels, order, rank
+  size_t const nn = static_cast<size_t>(nv > 0 ? nv : 1);
+  DevBuf deg(nn * 4), is_minor(nn * 4);
+  if (range > 0)
+    hipLaunchKernelGGL(compact_tally_kernel, dim3(grid_for(range)), dim3(kThreads), 0, stream,
+                       tally.as<unsigned int>(), flags.as<unsigned int>(), pos.as<int64_t>(),
+                       static_cast<int64_t>(range), deg.as<unsigned int>(), is_minor.as<unsigned int>());
+  tally.release();
   DevBuf order, rank;
-  degree_order_sources_first(stream, deg.as<unsigned int>(), majors_are_dst ? src32 : dst32, ne, nv, order, rank);
-  relabel_ids(stream, src32, ne, rank.as<int32_t>());
-  relabel_ids(stream, dst32, ne, rank.as<int32_t>());
+  degree_order_marked(stream, deg.as<unsigned int>(), is_minor.as<unsigned int>(), nv, order, rank);
   if (major_counts_out && nv > 0) {  // the degrees in the new order: the build's histogram, for free
     major_counts_out->alloc(static_cast<size_t>(nv) * 4);
     hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, deg.as<unsigned int>(),
                        order.as<int32_t>(), nv, major_counts_out->as<unsigned int>());
   }
-  // ---- number_map (new -> external) and the external -> new lookup
-  DevBuf nmap(static_cast<size_t>(nv > 0 ? nv : 1) * dtype_size(g.vertex_type));
+  // ---- number_map (new -> external) and the external -> new lookup; endpoints through the lookup
+  DevBuf nmap(nn * dtype_size(g.vertex_type));
   DevBuf lookup(rr * 4);
   if (range > 0) {
     if (wide)
@@ -737,6 +808,18 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
                          range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
                          nmap.as<int32_t>(), lookup.as<int32_t>());
   }
+  auto relabel = [&](ArrayView const* a, int32_t* out) {
+    if (a->size == 0) return;
+    int64_t n = static_cast<int64_t>(a->size);
+    if (wide)
+      hipLaunchKernelGGL((lookup_ids_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int64_t const*>(a->data), n, lo, lookup.as<int32_t>(), out);
+    else
+      hipLaunchKernelGGL((lookup_ids_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                         static_cast<int32_t const*>(a->data), n, lo, lookup.as<int32_t>(), out);
+  };
+  relabel(src, src32);
+  relabel(dst, dst32);
   CGA_HIP(hipGetLastError());
   CGA_HIP(hipStreamSynchronize(stream));
   g.num_vertices = g.num_global_vertices = nv;
