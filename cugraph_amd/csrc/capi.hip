@@ -199,7 +199,8 @@ Graph* make_graph(Handle const& h, cugraph_graph_properties_t const* props, Arra
   CompressedOut out = compress_coo(stream, n_major, n_minor, ne, majors, minors,
                                    weights ? weights->data : nullptr,
                                    weights ? dtype_size(weights->type) : 0,
-                                   major_counts.p ? major_counts.as<unsigned int>() : nullptr);
+                                   major_counts.p ? major_counts.as<unsigned int>() : nullptr,
+                                   g->degree_sorted);
   g->off64   = out.off64;
   g->offsets = out.offsets.detach();
   g->indices = static_cast<int32_t*>(out.indices.detach());

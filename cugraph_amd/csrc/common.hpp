@@ -258,7 +258,8 @@ CompressedOut compress_coo(hipStream_t stream,
                            int32_t const* minors,
                            void const* weights,
                            size_t weight_size,
-                           unsigned int const* major_counts = nullptr);
+                           unsigned int const* major_counts = nullptr,
+                           bool hubs_first = false);  // majors are in descending degree order
 
 // ties_in_input_order = false: equal minors of a LONG column may come out in any order (saves
 // half of the radix passes; the permutation stays valid)

@@ -277,25 +277,31 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(int32_t const* __rest
     else
       return static_cast<KeyT>(minors[e]);
   };
+  // majors inside the window [first, first + kLdsMajors) go through LDS, the others (none when the
+  // span fits the window; the cold majority of a degree-sorted graph, whose hubs are the window)
+  // through global atomics
   int32_t first;
-  if (!span_window(majors, beg, end, &first)) {
-    for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
-      int32_t const m = majors[e];
-      keys[static_cast<unsigned int>(offsets[m]) + atomicAdd(&cursor[m], 1u)] = key_of(e);
-    }
-    return;
-  }
+  (void)span_window(majors, beg, end, &first);
   for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) lds_pos[k] = 0u;
   __syncthreads();
-  for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) atomicAdd(&lds_pos[majors[e] - first], 1u);
+  for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
+    unsigned int const d = static_cast<unsigned int>(majors[e] - first);
+    if (d < static_cast<unsigned int>(kLdsMajors)) atomicAdd(&lds_pos[d], 1u);
+  }
   __syncthreads();
   for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) {
     unsigned int const c = lds_pos[k];
     if (c) lds_pos[k] = static_cast<unsigned int>(offsets[first + k]) + atomicAdd(&cursor[first + k], c);
   }
   __syncthreads();
-  for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x)
-    keys[atomicAdd(&lds_pos[majors[e] - first], 1u)] = key_of(e);
+  for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
+    int32_t const m      = majors[e];
+    unsigned int const d = static_cast<unsigned int>(m - first);
+    unsigned int const pos = d < static_cast<unsigned int>(kLdsMajors)
+                               ? atomicAdd(&lds_pos[d], 1u)
+                               : static_cast<unsigned int>(offsets[m]) + atomicAdd(&cursor[m], 1u);
+    keys[pos] = key_of(e);
+  }
 }
 
 // ------------------------------------------------------------------ 4. per-column ordering
@@ -341,14 +347,27 @@ __global__ void classify_columns_kernel(OffT const* __restrict__ offsets, int64_
                                         int32_t* __restrict__ big_list,
                                         unsigned int* __restrict__ n_lists /* [2] */)
 {
+  // one atomic per wave and list: the lanes that append share a reservation
+  int const lane = threadIdx.x & 63;
+  unsigned long long const below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_major; v += stride) {
-    int64_t deg = static_cast<int64_t>(offsets[v + 1] - offsets[v]);
-    if (deg > 64) {
-      if (deg <= kMedCap)
-        med_list[atomicAdd(&n_lists[0], 1u)] = static_cast<int32_t>(v);
-      else
-        big_list[atomicAdd(&n_lists[1], 1u)] = static_cast<int32_t>(v);
+  int64_t const rounds = (n_major + stride - 1) / stride;
+  for (int64_t r = 0; r < rounds; ++r) {
+    int64_t v   = r * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t deg = v < n_major ? static_cast<int64_t>(offsets[v + 1] - offsets[v]) : 0;
+    bool const med = deg > 64 && deg <= kMedCap, big = deg > kMedCap;
+    unsigned long long const m_med = __ballot(med), m_big = __ballot(big);
+    if (m_med) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(&n_lists[0], static_cast<unsigned int>(__popcll(m_med)));
+      base = __shfl(base, 0, 64);
+      if (med) med_list[base + __popcll(m_med & below)] = static_cast<int32_t>(v);
+    }
+    if (m_big) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(&n_lists[1], static_cast<unsigned int>(__popcll(m_big)));
+      base = __shfl(base, 0, 64);
+      if (big) big_list[base + __popcll(m_big & below)] = static_cast<int32_t>(v);
     }
   }
 }
@@ -407,6 +426,7 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__
 {
   __shared__ unsigned int base[256];
   __shared__ unsigned int wave_cnt[16][256];
+  __shared__ int one_digit;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   unsigned int n_cols        = *n_list;
@@ -416,13 +436,21 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__
     int64_t deg = static_cast<int64_t>(offsets[v + 1] - b);
     KeyT* in    = keys + b;
     KeyT* out   = tmp + b;
+    int moved   = 0;  // passes that moved the keys to the other buffer
     for (int p = 0; p < passes.n; ++p) {
       int sh = passes.shift[p];
       if (threadIdx.x < 256) base[threadIdx.x] = 0;
+      if (threadIdx.x == 0) one_digit = 0;
       __syncthreads();
       for (int64_t i = threadIdx.x; i < deg; i += blockDim.x)
         atomicAdd(&base[(unsigned int)(in[i] >> sh) & 255u], 1u);
       __syncthreads();
+      // every key has the same digit (bits above what a column's keys differ in): nothing to do
+      if (threadIdx.x < 256 && static_cast<int64_t>(base[threadIdx.x]) == deg) one_digit = 1;
+      __syncthreads();
+      bool const skip = one_digit != 0;
+      __syncthreads();  // (the next pass resets the flag)
+      if (skip) continue;
       if (wave == 0) {  // exclusive scan of 256 counters by one wave, 4 per lane
         unsigned int c0 = base[lane * 4], c1 = base[lane * 4 + 1], c2 = base[lane * 4 + 2],
                      c3 = base[lane * 4 + 3];
@@ -472,8 +500,9 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__
       KeyT* t = in;
       in      = out;
       out     = t;
+      ++moved;
     }
-    if (passes.n & 1) {  // result sits in tmp
+    if (moved & 1) {  // result sits in tmp
       for (int64_t i = threadIdx.x; i < deg; i += blockDim.x) out[i] = in[i];
     }
     __syncthreads();
@@ -585,12 +614,15 @@ template <typename OffT>
 CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                             int32_t const* majors, int32_t const* minors, void const* weights,
                             size_t weight_size, bool want_perm = false,
-                            unsigned int const* major_counts = nullptr, bool ties_in_input_order = true)
+                            unsigned int const* major_counts = nullptr, bool ties_in_input_order = true,
+                            bool hubs_first = false)
 {
   CompressedOut out;
   // long columns (512 edges or more on average): LDS-privatised histogram and scatter (hist_lds_kernel)
-  bool const few_majors = sizeof(OffT) == 4 && n_edges >= (int64_t{1} << 16) && n_edges / 512 >= n_major &&
-                          std::getenv("CUGRAPH_AMD_BUILD_NO_LDS") == nullptr;
+  bool const no_lds     = std::getenv("CUGRAPH_AMD_BUILD_NO_LDS") != nullptr;
+  bool const few_majors = sizeof(OffT) == 4 && n_edges >= (int64_t{1} << 16) && n_edges / 512 >= n_major && !no_lds;
+  // majors in descending degree order: the first kLdsMajors of them take a large share of the edges
+  bool const lds_scatter = few_majors || (sizeof(OffT) == 4 && hubs_first && n_edges >= (int64_t{1} << 16) && !no_lds);
   size_t const lds_bytes = static_cast<size_t>(kLdsMajors) * sizeof(unsigned int);
   int const lds_grid     = 1024;
   out.off64 = sizeof(OffT) == 8;
@@ -626,7 +658,7 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
   auto scatter = [&](auto* keys) {
     using KeyT = std::remove_pointer_t<decltype(keys)>;
     if constexpr (sizeof(OffT) == 4) {
-      if (few_majors) {
+      if (lds_scatter) {
         auto kern = scatter_lds_kernel<KeyT>;
         CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -702,14 +734,14 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
 
 CompressedOut compress_coo(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                            int32_t const* majors, int32_t const* minors, void const* weights,
-                           size_t weight_size, unsigned int const* major_counts)
+                           size_t weight_size, unsigned int const* major_counts, bool hubs_first)
 {
   // same switch as the reference's edge_t choice (cpp/src/c_api/graph_sg.cpp:568-572)
   if (n_edges < 0x7fffffffLL)
     return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
-                                  weight_size, false, major_counts);
+                                  weight_size, false, major_counts, true, hubs_first);
   return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
-                                weight_size, false, major_counts);
+                                weight_size, false, major_counts, true, hubs_first);
 }
 
 // exclusive scan of 32-bit counts into 64-bit positions, out[n] = total (stream compaction helper)
