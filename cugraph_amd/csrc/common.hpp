@@ -267,6 +267,9 @@ CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_m
                                 int64_t n_edges, int32_t const* majors, int32_t const* minors,
                                 bool ties_in_input_order = true);
 
+// counts[key] += occurrences (counts zeroed by the caller); hubs_first: small keys are the frequent ones
+void histogram_u32(hipStream_t stream, int32_t const* keys, int64_t n, unsigned int* counts, bool hubs_first);
+
 // offsets -> one major id per edge (the inverse of the histogram+scan)
 void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,
                     int64_t n_edges, int32_t* majors_out);

@@ -130,14 +130,20 @@ __global__ __launch_bounds__(1024) void hist_lds_kernel(int32_t const* __restric
   int64_t const span = (n + gridDim.x - 1) / gridDim.x;
   int64_t const beg = blockIdx.x * span, end = beg + span < n ? beg + span : n;
   if (beg >= end) return;
+  // keys inside the window [first, first + kLdsMajors) are counted in LDS, the others (none when
+  // the span fits the window) with global atomics
   int32_t first;
-  if (!span_window(keys, beg, end, &first)) {
-    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&counts[keys[i]], 1u);
-    return;
-  }
+  (void)span_window(keys, beg, end, &first);
   for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) lds_count[k] = 0u;
   __syncthreads();
-  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&lds_count[keys[i] - first], 1u);
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    int32_t const key    = keys[i];
+    unsigned int const d = static_cast<unsigned int>(key - first);
+    if (d < static_cast<unsigned int>(kLdsMajors))
+      atomicAdd(&lds_count[d], 1u);
+    else
+      atomicAdd(&counts[key], 1u);
+  }
   __syncthreads();
   for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x)
     if (lds_count[k]) atomicAdd(&counts[first + k], lds_count[k]);
@@ -731,6 +737,23 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
 }
 
 }  // namespace
+
+// counts[key] += occurrences of key; hubs_first: small keys are the frequent ones (ids of a
+// degree-sorted graph), counted through an LDS window
+void histogram_u32(hipStream_t stream, int32_t const* keys, int64_t n, unsigned int* counts, bool hubs_first)
+{
+  if (n == 0) return;
+  if (hubs_first && n >= (int64_t{1} << 16) && std::getenv("CUGRAPH_AMD_BUILD_NO_LDS") == nullptr) {
+    CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(hist_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(kLdsMajors * sizeof(unsigned int))));
+    hipLaunchKernelGGL(hist_lds_kernel, dim3(1024), dim3(1024), kLdsMajors * sizeof(unsigned int), stream, keys, n,
+                       counts);
+  } else {
+    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, keys, n, counts);
+  }
+  CGA_HIP(hipGetLastError());
+}
 
 CompressedOut compress_coo(hipStream_t stream, int64_t n_major, int64_t n_minor, int64_t n_edges,
                            int32_t const* majors, int32_t const* minors, void const* weights,

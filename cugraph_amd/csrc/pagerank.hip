@@ -1630,6 +1630,17 @@ __global__ void slots_of_indices_kernel(int32_t const* __restrict__ indices, int
 // vertices: the cold lines of the gathered vector hold 2.5 times as many useful values, and the
 // smaller source space lets the XS tiles take more rows (build_xs).  The out-weight sums are
 // taken here, while the indices still are vertex ids.
+// unweighted graphs: the out-weight sum of a vertex is how often it occurs as a source, and "occurs
+// at all" is the source mark -- one pass of 4-byte atomics instead of fp64 atomics plus a marking pass
+__global__ void counts_to_sums_kernel(unsigned int* __restrict__ counts, int64_t n, double* __restrict__ sums)
+{
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    unsigned int const c = counts[v];
+    sums[v]              = static_cast<double>(c);
+    counts[v]            = c ? 1u : 0u;
+  }
+}
+
 void build_compact(hipStream_t stream, Graph const& cg, PullPlan& plan)
 {
   char const* env = std::getenv("CUGRAPH_AMD_COMPACT");
@@ -1639,12 +1650,18 @@ void build_compact(hipStream_t stream, Graph const& cg, PullPlan& plan)
   int64_t const n = cg.num_vertices, ne = cg.num_edges;
   if (n == 0 || ne == 0 || (!forced && ne < (int64_t(1) << 22))) return;
   plan.out_w_sums.alloc(static_cast<size_t>(n) * sizeof(double));
-  compute_source_sums(stream, cg, plan.out_w_sums.as<double>());
   plan.have_out_w = true;
   DevBuf flags(static_cast<size_t>(n) * 4), pos(static_cast<size_t>(n + 1) * 8);
   CGA_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, stream));
-  hipLaunchKernelGGL(mark_sources_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, cg.indices, ne,
-                     flags.as<unsigned int>());
+  if (cg.weights) {
+    compute_source_sums(stream, cg, plan.out_w_sums.as<double>());
+    hipLaunchKernelGGL(mark_sources_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, cg.indices, ne,
+                       flags.as<unsigned int>());
+  } else {
+    histogram_u32(stream, cg.indices, ne, flags.as<unsigned int>(), cg.degree_sorted);
+    hipLaunchKernelGGL(counts_to_sums_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                       flags.as<unsigned int>(), n, plan.out_w_sums.as<double>());
+  }
   exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n, pos.as<int64_t>());
   int64_t n_slots = 0;
   CGA_HIP(hipMemcpyAsync(&n_slots, pos.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, stream));
