@@ -397,6 +397,48 @@ def test_renumber_ids_spanning_more_than_int31(ids, transposed, monkeypatch):
             make_sg_graph(ext[src], ext[dst], wgt, store_transposed=transposed, renumber=True, vertices=ext[:-5])
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_build_through_lds_windows_equals_global_atomics(weighted, monkeypatch):
+    """The graph and plan builds count and scatter hub majors / long columns through LDS windows
+    (graph_build.hip: hist_lds_kernel, scatter_lds_kernel).  The compressed graph must be the same
+    array for array as with global atomics alone, and equal to the oracle's CSC; PageRank through
+    the plan built either way agrees with the oracle."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0")
+    scale = 16
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=21, scramble=True)
+    wgt = oracle.rmat_weights(ne, seed=22).astype(np.float32) if weighted else None
+    got = {}
+    for mode in ("lds", "global"):
+        if mode == "global":
+            monkeypatch.setenv("CUGRAPH_AMD_BUILD_NO_LDS", "1")
+        g, h = make_sg_graph(src, dst, wgt, multigraph=True, renumber=True, vertices=np.arange(nv, dtype=np.int32))
+        off, idx, w, nmap = compressed_arrays(g, h)
+        v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-7, 500, False,
+                                  fail_on_nonconvergence=False)
+        pr = np.empty(nv)
+        pr[v.cpu().numpy()] = r.cpu().numpy()
+        got[mode] = (off, idx, w, nmap, pr, bool(conv))
+    for a, b in zip(got["lds"][:4], got["global"][:4]):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    off, idx, w, nmap = got["lds"][:4]
+    inv = np.empty(nv, np.int32)
+    inv[nmap] = np.arange(len(nmap), dtype=np.int32)
+    o_off, o_idx, o_w = oracle.csc_lexsort(len(nmap), inv[src], inv[dst], wgt)
+    assert np.array_equal(off.astype(np.int64), o_off) and np.array_equal(idx, o_idx)
+    if weighted:  # equal (dst, src) pairs keep their input order, weights follow
+        assert np.array_equal(w, o_w)
+    c_off, c_idx, perm = oracle.compress(nv, dst, src)
+    o_pr, _, o_conv = oracle.pagerank(nv, c_off, c_idx, None if wgt is None else wgt[perm], dtype=np.float64,
+                                      alpha=0.85, epsilon=1e-7, max_iterations=500)
+    for mode in got:
+        assert got[mode][5] == o_conv
+        assert np.max(np.abs(got[mode][4][:len(o_pr)] - o_pr)) <= 1e-6
+
+
 def test_unknown_vertex_ids_rejected():
     from cugraph_amd import pylibcugraph as plc
 
