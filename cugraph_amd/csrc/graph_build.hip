@@ -759,8 +759,9 @@ CompressedOut compress_coo(hipStream_t stream, int64_t n_major, int64_t n_minor,
                            int32_t const* majors, int32_t const* minors, void const* weights,
                            size_t weight_size, unsigned int const* major_counts, bool hubs_first)
 {
-  // same switch as the reference's edge_t choice (cpp/src/c_api/graph_sg.cpp:568-572)
-  if (n_edges < 0x7fffffffLL)
+  // same switch as the reference's edge_t choice (cpp/src/c_api/graph_sg.cpp:568-572);
+  // CUGRAPH_AMD_FORCE_OFF64=1 takes the 64-bit side on any graph (so that tests reach its kernels)
+  if (n_edges < 0x7fffffffLL && std::getenv("CUGRAPH_AMD_FORCE_OFF64") == nullptr)
     return compress_impl<int32_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,
                                   weight_size, false, major_counts, true, hubs_first);
   return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, weights,

@@ -439,6 +439,61 @@ def test_build_through_lds_windows_equals_global_atomics(weighted, monkeypatch):
         assert np.max(np.abs(got[mode][4][:len(o_pr)] - o_pr)) <= 1e-6
 
 
+@pytest.mark.parametrize("xs_tiles", [False, True])
+@pytest.mark.parametrize("dtype,weighted", [(np.float32, False), (np.float64, True)])
+def test_sixty_four_bit_offsets(xs_tiles, dtype, weighted, monkeypatch):
+    """Graphs of 2^31 - 1 edges or more keep 64-bit offsets (graph_sg.cpp:568-572); that side of the
+    build, the plan and every iteration kernel is a separate instantiation which only an 80 GB graph
+    would reach.  CUGRAPH_AMD_FORCE_OFF64 takes it on a small graph: same CSC, same ranks, same
+    iteration count as the oracle, with and without XS tiles, plus the transpose and a Katz run."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_FORCE_OFF64", "1")
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0" if xs_tiles else str(1 << 40))
+    monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1" if xs_tiles else "0")
+    scale = 14
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=31, scramble=True)
+    wgt = oracle.rmat_weights(ne, seed=32).astype(dtype) if weighted else None
+    for transposed in (True, False):
+        g, h = make_sg_graph(src, dst, wgt, vertices=np.arange(nv, dtype=np.int32), multigraph=True,
+                             renumber=True, store_transposed=transposed)
+        off, idx, w, nmap = compressed_arrays(g, h)
+        assert off.dtype == np.int64
+        inv = np.empty(nv, np.int32)
+        inv[nmap] = np.arange(nv, dtype=np.int32)
+        major, minor = (inv[dst], inv[src]) if transposed else (inv[src], inv[dst])
+        o_off, o_idx, o_w = oracle.csc_lexsort(nv, minor, major, wgt)
+        assert np.array_equal(off, o_off) and np.array_equal(idx, o_idx)
+        if weighted:
+            assert np.array_equal(w, o_w)
+        pv = np.array([5, 77, 4000], np.int32)
+        pvals = np.array([0.3, 0.3, 0.4], dtype if weighted else np.float32)
+        eps = 1e-7 if dtype == np.float32 else 1e-11
+        # (a graph stored the other way round is transposed in place by the call, pagerank.cpp:105-110)
+        v, r, conv = plc.personalized_pagerank(h, g, None, None, None, None, to_dev(pv), to_dev(pvals),
+                                               0.85, eps, 500, False, fail_on_nonconvergence=False)
+        c_off, c_idx, perm = oracle.compress(nv, dst, src)
+        o_pr, o_it, o_conv = oracle.pagerank(nv, c_off, c_idx, None if wgt is None else wgt[perm],
+                                             dtype=np.float64, alpha=0.85, epsilon=eps, max_iterations=500,
+                                             pers_vertices=pv, pers_values=pvals)
+        got = np.empty(nv)
+        got[v.cpu().numpy()] = r.cpu().numpy()
+        assert bool(conv) == o_conv
+        assert np.max(np.abs(got - o_pr)) <= (1e-6 if dtype == np.float32 else 1e-10)
+        if transposed:
+            from oracle import np_centrality as npc
+
+            w64 = None if wgt is None else wgt.astype(np.float64)
+            alpha = 0.5 / np.bincount(dst, weights=w64, minlength=nv).max()
+            kv, kr = plc.katz_centrality(h, g, None, alpha, 1.0, 1e-9, 1000, False)
+            want, _ = npc.katz_centrality(nv, src, dst, wgt, alpha=alpha, beta=1.0, epsilon=1e-9, max_iterations=1000)
+            kz = np.empty(nv)
+            kz[kv.cpu().numpy()] = kr.cpu().numpy()
+            assert np.max(np.abs(kz - want)) < (2e-5 if dtype == np.float32 else 1e-10)
+
+
 def test_unknown_vertex_ids_rejected():
     from cugraph_amd import pylibcugraph as plc
 
