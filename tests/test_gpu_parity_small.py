@@ -494,6 +494,54 @@ def test_sixty_four_bit_offsets(xs_tiles, dtype, weighted, monkeypatch):
             assert np.max(np.abs(kz - want)) < (2e-5 if dtype == np.float32 else 1e-10)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_low_degree_rows_ordered_by_their_sources(weighted, monkeypatch):
+    """On big graphs the renumbering orders the rows of in-degree 1, 2 and 3 -- inside each class,
+    where the order is free -- by their smallest source (renumber.hip), so that the threads of the
+    thread-per-row bucket gather from neighbouring slots.  Forced on a small graph here: still a
+    descending-degree numbering, the rows of degree >= 4 and of degree 0 keep the plain tie order,
+    the stored graph is the oracle's CSC of the relabelled edges, the smallest sources of a class
+    ascend (up to the few rows whose sources are low-degree rows themselves and moved with them),
+    and PageRank equals the oracle's by vertex id."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    scale = 14
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=41, scramble=True)
+    wgt = oracle.rmat_weights(ne, seed=42).astype(np.float32) if weighted else None
+    maps = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CUGRAPH_AMD_RENUMBER_LOCALITY", mode)
+        g, h = make_sg_graph(src, dst, wgt, vertices=np.arange(nv, dtype=np.int32), multigraph=True, renumber=True)
+        off, idx, w, nmap = compressed_arrays(g, h)
+        maps[mode] = nmap
+        deg = np.diff(off)
+        assert np.all(deg[:-1] >= deg[1:]) and sorted(nmap.tolist()) == list(range(nv))
+        inv = np.empty(nv, np.int32)
+        inv[nmap] = np.arange(nv, dtype=np.int32)
+        o_off, o_idx, o_w = oracle.csc_lexsort(nv, inv[src], inv[dst], wgt)
+        assert np.array_equal(off.astype(np.int64), o_off) and np.array_equal(idx, o_idx)
+        if weighted:
+            assert np.array_equal(w, o_w)
+        v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-7, 500, False, fail_on_nonconvergence=False)
+        c_off, c_idx, perm = oracle.compress(nv, dst, src)
+        o_pr, _, o_conv = oracle.pagerank(nv, c_off, c_idx, None if wgt is None else wgt[perm], dtype=np.float64,
+                                          alpha=0.85, epsilon=1e-7, max_iterations=500)
+        got = np.empty(nv)
+        got[v.cpu().numpy()] = r.cpu().numpy()
+        assert bool(conv) == o_conv and np.max(np.abs(got - o_pr)) <= 1e-6
+        if mode == "1":
+            low = (deg >= 1) & (deg <= 3)
+            assert np.array_equal(maps["0"][~low], nmap[~low])  # the other classes are untouched
+            assert not np.array_equal(maps["0"][low], nmap[low])
+            first_src = np.array([idx[off[r]] for r in np.flatnonzero(low)])  # columns are sorted: the smallest
+            for d in (1, 2, 3):
+                fs = first_src[deg[low] == d]
+                assert len(fs) > 100 and np.mean(fs[:-1] <= fs[1:]) > 0.9
+                assert sorted(maps["0"][deg == d].tolist()) == sorted(nmap[deg == d].tolist())
+
+
 def test_unknown_vertex_ids_rejected():
     from cugraph_amd import pylibcugraph as plc
 
