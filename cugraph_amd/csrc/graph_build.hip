@@ -430,8 +430,9 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__
                                                         unsigned int const* __restrict__ n_list,
                                                         RadixPasses passes)
 {
+  constexpr int R = 3;  // keys per thread and chunk (48 KiB of counters): a chunk is R * 16 runs of 64 keys ("virtual waves")
   __shared__ unsigned int base[256];
-  __shared__ unsigned int wave_cnt[16][256];
+  __shared__ unsigned int wave_cnt[16 * R][256];
   __shared__ int one_digit;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -472,25 +473,32 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__
         base[lane * 4 + 3] = ex + c0 + c1 + c2;
       }
       __syncthreads();
-      for (int64_t chunk = 0; chunk < deg; chunk += blockDim.x) {
-        for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) (&wave_cnt[0][0])[i] = 0;
+      for (int64_t chunk = 0; chunk < deg; chunk += R * blockDim.x) {
+        for (int i = threadIdx.x; i < 16 * R * 256; i += blockDim.x) (&wave_cnt[0][0])[i] = 0;
         __syncthreads();
-        int64_t i  = chunk + threadIdx.x;
-        bool valid = i < deg;
-        KeyT k     = valid ? in[i] : 0;
-        unsigned int d = (unsigned int)(k >> sh) & 255u;
-        unsigned long long m = __ballot(valid);
+        KeyT k[R];
+        unsigned int d[R], rank[R];
+        bool valid[R];
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-          unsigned long long bal = __ballot(valid && ((d >> bit) & 1u));
-          m &= ((d >> bit) & 1u) ? bal : ~bal;
+        for (int r = 0; r < R; ++r) {
+          int64_t i = chunk + r * (int64_t)blockDim.x + threadIdx.x;
+          valid[r]  = i < deg;
+          k[r]      = valid[r] ? in[i] : 0;
+          d[r]      = (unsigned int)(k[r] >> sh) & 255u;
+          // lanes of this run that hold the same digit
+          unsigned long long m = __ballot(valid[r]);
+#pragma unroll
+          for (int bit = 0; bit < 8; ++bit) {
+            unsigned long long bal = __ballot(valid[r] && ((d[r] >> bit) & 1u));
+            m &= ((d[r] >> bit) & 1u) ? bal : ~bal;
+          }
+          rank[r] = __popcll(m & lt_mask);
+          if (valid[r] && rank[r] == 0) wave_cnt[r * 16 + wave][d[r]] = __popcll(m);
         }
-        unsigned int rank = __popcll(m & lt_mask);
-        if (valid && rank == 0) wave_cnt[wave][d] = __popcll(m);
         __syncthreads();
         if (threadIdx.x < 256) {
           unsigned int run = base[threadIdx.x];
-          for (int w = 0; w < 16; ++w) {
+          for (int w = 0; w < 16 * R; ++w) {
             unsigned int t            = wave_cnt[w][threadIdx.x];
             wave_cnt[w][threadIdx.x] = run;
             run += t;
@@ -498,7 +506,9 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(OffT const* __restrict__
           base[threadIdx.x] = run;
         }
         __syncthreads();
-        if (valid) out[wave_cnt[wave][d] + rank] = k;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (valid[r]) out[wave_cnt[r * 16 + wave][d[r]] + rank[r]] = k[r];
         __syncthreads();
       }
       // the next pass reads what this one wrote (same workgroup, global memory)
