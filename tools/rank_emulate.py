@@ -60,7 +60,16 @@ rank_l[orders[me]] = torch.arange(last - first, dtype=torch.int32, device="cuda"
 g = eng.make_local_graph(slot_of[s_l.long()], rank_l[(d_l - first).long()] + first, None, first, last, nv,
                          num_source_slots=n_slots, x_pos=my_x_pos, hot_slots=hot)
 n_local_edges = int(s_l.numel())
-del s_l, d_l
+# how much of the gathered vector this rank's edges ever read (the case for a personalised exchange)
+ref = torch.zeros(n_slots, dtype=torch.bool, device="cuda")
+ref[slot_of[s_l.long()].long()] = True
+n_ref = int(ref.sum())
+n_ref_remote = n_ref - int(ref[my_x_pos[my_x_pos >= 0].long()].sum())
+n_own = int((my_x_pos >= 0).sum())
+print(f"rank {me} of {world} reads {n_ref} of {n_slots} slots ({100.0 * n_ref / n_slots:.1f} %); "
+      f"{n_ref_remote} of the {n_slots - n_own} slots of other ranks ({100.0 * n_ref_remote / max(n_slots - n_own, 1):.1f} %)",
+      flush=True)
+del ref, s_l, d_l
 ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
 sums = outdeg[first:last][orders[me]].to(torch.float32)
 sess = eng.make_session(g, alpha=0.85, epsilon=0.0, precomputed_vertex_out_weight_vertices=ids,
