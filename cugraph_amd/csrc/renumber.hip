@@ -272,11 +272,17 @@ __global__ void hash_insert_kernel(IdT const* __restrict__ ids, int64_t n, unsig
       continue;
     }
     unsigned long long h = mix64(v) & mask;
-    // the table has at least twice as many slots as keys: a probe always ends
+    // the table has twice as many slots as keys (or 2^32, more than twice the 2^31 ids a graph
+    // may have): a probe ends, unless there are more distinct ids than any graph here can hold
+    unsigned long long probes = 0;
     while (true) {
       unsigned long long const old = atomicCAS(&table[h], kEmptySlot, v);
       if (old == kEmptySlot || old == v) break;
       h = (h + 1) & mask;
+      if (++probes > mask) {
+        *saw_sentinel = 2u;
+        break;
+      }
     }
   }
 }
@@ -615,7 +621,7 @@ void renumber_sparse_ids(Handle const& h, Graph& g, ArrayView const* vertices, A
   bool const wide    = src->type == INT64;
   int64_t const n_keys = vertices ? static_cast<int64_t>(vertices->size) : 2 * ne;
   unsigned long long slots = 1024;
-  while (slots < 2ull * static_cast<unsigned long long>(n_keys)) slots <<= 1;
+  while (slots < 2ull * static_cast<unsigned long long>(n_keys) && slots < (1ull << 32)) slots <<= 1;
   DevBuf table(slots * 8), saw(4);
   CGA_HIP(hipMemsetAsync(saw.p, 0, 4, stream));
   {
@@ -652,6 +658,7 @@ void renumber_sparse_ids(Handle const& h, Graph& g, ArrayView const* vertices, A
   CGA_HIP(hipMemcpyAsync(&nv, upos.as<int64_t>() + slots, 8, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipMemcpyAsync(&h_saw, saw.p, 4, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
+  CGA_EXPECTS(h_saw != 2, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "2^31 or more vertices are not supported");
   CGA_EXPECTS(h_saw == 0, CUGRAPH_NOT_IMPLEMENTED, "renumber=TRUE: the smallest 64-bit integer as a vertex id");
   CGA_EXPECTS(nv < 0x7fffffffLL, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "2^31 or more vertices are not supported");
   size_t const nn = static_cast<size_t>(nv > 0 ? nv : 1);
