@@ -553,6 +553,47 @@ def test_low_degree_rows_ordered_by_their_sources(weighted, monkeypatch):
                 assert sorted(maps["0"][deg == d].tolist()) == sorted(nmap[deg == d].tolist())
 
 
+@pytest.mark.parametrize("name", [
+    "test_pagerank", "test_pagerank_4", "test_pagerank_non_convergence",
+    "test_personalized_pagerank", "test_personalized_pagerank_non_convergence"])
+def test_mg_c_api_goldens_over_rccl(golden, name):
+    """cpp/tests/c_api/mg_pagerank_test.c:396-560 (the multi-GPU C-API test holds the same vectors as
+    pagerank_test.c): through cugraph_amd.mg.pagerank -- HIP engine, RCCL collectives, one rank --
+    with the personalization handed over as a per-rank share; the reference's 0.001 relative."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from cugraph_amd import mg, pylibcugraph as plc
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        block = golden["c_api"]
+        case = block["cases"][name]
+        src, dst, wgt = case_arrays(case)
+        pers = None
+        if "pers_vertices" in case:
+            pers = (to_dev(np.array(case["pers_vertices"], np.int32)), to_dev(np.array(case["pers_values"], np.float32)))
+        h = plc.ResourceHandle(rank=0, comm_size=1)
+        verts, vals, conv = mg.pagerank(h, plc.GraphProperties(is_multigraph=False), to_dev(src), to_dev(dst),
+                                        to_dev(wgt), case["num_vertices"], alpha=case["alpha"], tol=case["epsilon"],
+                                        max_iter=case["max_iterations"], personalization=pers, sharded=pers is not None,
+                                        fail_on_nonconvergence=False)
+        assert bool(conv) == (not case["allow_nonconvergence"])
+        _expect_close(vals.cpu().numpy(), np.array(case["expected"])[verts.cpu().numpy()], block["rel_tol"])
+        if case["allow_nonconvergence"]:
+            with pytest.raises(plc.FailedToConvergeError):
+                mg.pagerank(h, plc.GraphProperties(is_multigraph=False), to_dev(src), to_dev(dst), to_dev(wgt),
+                            case["num_vertices"], alpha=case["alpha"], tol=case["epsilon"],
+                            max_iter=case["max_iterations"], personalization=pers)
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def test_unknown_vertex_ids_rejected():
     from cugraph_amd import pylibcugraph as plc
 
