@@ -129,7 +129,11 @@ typedef struct {
 /* graph.h:116 (impl cpp/src/c_api/graph_sg.cpp:508-633).  Inputs are copied; the caller keeps
  * its arrays.  edge_ids / edge_type_ids are accepted for signature compatibility and ignored
  * (PageRank never reads them).  renumber=TRUE relabels vertices by descending in-degree and the
- * result carries the external ids (renumber_edgelist_impl.cuh:238-607). */
+ * result carries the external ids (renumber_edgelist_impl.cuh:238-607); the ids may be any int32 /
+ * int64 values.  do_expensive_check verifies what the reference verifies
+ * (create_graph_from_edgelist_impl.cuh:72-126, 895-921): no duplicates in `vertices`, consecutive
+ * ids from 0 without renumbering, the is_symmetric and is_multigraph flags against the edge list;
+ * a failure is CUGRAPH_UNKNOWN_ERROR with the reference's message (graph_sg.cpp:627-629). */
 cugraph_error_code_t cugraph_graph_create_sg(
   const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
   const cugraph_type_erased_device_array_view_t* vertices,
