@@ -96,7 +96,9 @@ class Graph:
     # ------------------------------------------------------------------ intake
     def from_pandas_edgelist(self, pdf, source="source", destination="destination", edge_attr=None,
                              weight=None, renumber=True, store_transposed=False,
-                             legacy_renum_only=False, vertices=None):
+                             legacy_renum_only=False, vertices=None, _as_given=False):
+        """_as_given (internal, from_cudf_adjlist): the rows are the stored edges, both directions of
+        an undirected edge included; nothing is symmetrised or dropped"""
         import pandas as pd
 
         if not isinstance(pdf, pd.DataFrame):
@@ -141,7 +143,9 @@ class Graph:
             if w.dtype not in (np.float32, np.float64):
                 w = w.astype(np.float64)
             df["weights"] = w
-        if not self.is_directed():
+        if _as_given:
+            pass
+        elif not self.is_directed():
             df = _symmetrize(df, self.multi)
         elif not self.multi:
             # simpleGraph.py:306-312: a Graph (not MultiGraph) drops parallel edges
@@ -156,14 +160,60 @@ class Graph:
     # cuDF is CUDA-only; the method name is kept so reference call sites read the same
     from_cudf_edgelist = from_pandas_edgelist
 
+    def from_cudf_adjlist(self, offset_col, index_col, value_col=None, renumber=True, store_transposed=False):
+        """graph_classes.py:206-271: a graph from its adjacency list (CSR: offsets over sources of
+        size V + 1, destination indices of size E, optional weights).  Undirected edges must be
+        stored in both directions.  Vertex ids are the row numbers, so a vertex without edges
+        still counts."""
+        import pandas as pd
+
+        if self.edgelist is not None:
+            raise RuntimeError("Graph already has values")
+        off = np.asarray(offset_col).astype(np.int64)
+        idx = np.asarray(index_col)
+        if off.ndim != 1 or len(off) < 1 or off[0] != 0 or off[-1] != len(idx) or np.any(np.diff(off) < 0):
+            raise ValueError("offset_col must hold V + 1 non-decreasing offsets from 0 to the number of edges")
+        nv = len(off) - 1
+        if len(idx) and (idx.min() < 0 or idx.max() >= nv):
+            raise ValueError("index_col must hold vertex ids in [0, V)")
+        id_dtype = idx.dtype if idx.dtype in (np.int32, np.int64) else np.int32
+        pdf = pd.DataFrame({"src": np.repeat(np.arange(nv, dtype=id_dtype), np.diff(off)), "dst": idx.astype(id_dtype)})
+        if value_col is not None:
+            pdf["weight"] = np.asarray(value_col)
+        return self.from_pandas_edgelist(pdf, "src", "dst", None if value_col is None else "weight",
+                                         renumber=renumber, store_transposed=store_transposed,
+                                         vertices=np.arange(nv, dtype=id_dtype), _as_given=True)
+
+    def from_pandas_adjacency(self, pdf):
+        """graph_classes.py:443-457: adjacency matrix as a DataFrame, column labels name the nodes"""
+        import pandas as pd
+
+        if not isinstance(pdf, pd.DataFrame):
+            raise TypeError("pdf input is not a Pandas DataFrame")
+        return self.from_numpy_array(pdf.to_numpy(), pdf.columns)
+
     def from_numpy_array(self, np_array, nodes=None):
+        """graph_classes.py:459-485: adjacency matrix; non-zero entries are the weighted edges"""
         import pandas as pd
 
         a = np.asarray(np_array)
-        src, dst = np.nonzero(a)
-        pdf = pd.DataFrame({"src": src.astype(np.int32), "dst": dst.astype(np.int32),
-                            "weight": a[src, dst].astype(np.float64)})
-        return self.from_pandas_edgelist(pdf, "src", "dst", "weight", renumber=False)
+        if len(a.shape) != 2:
+            raise ValueError("np_array is not a 2D matrix")
+        src, dst = a.nonzero()
+        weight = a[src, dst]
+        if nodes is not None:
+            nodes = np.asarray(nodes)
+            pdf = pd.DataFrame({"src": nodes[src], "dst": nodes[dst]})
+        else:
+            pdf = pd.DataFrame({"src": src.astype(np.int32), "dst": dst.astype(np.int32)})
+        pdf["weight"] = weight if weight.dtype in (np.float32, np.float64) else weight.astype(np.float64)
+        return self.from_pandas_edgelist(pdf, "src", "dst", edge_attr="weight")
+
+    def from_numpy_matrix(self, np_matrix):
+        """graph_classes.py:487-500"""
+        if not isinstance(np_matrix, np.matrix):
+            raise TypeError("np_matrix input is not a Numpy matrix")
+        return self.from_numpy_array(np.asarray(np_matrix))
 
     def _make_plc_graph(self):
         import torch

@@ -276,3 +276,55 @@ def test_string_and_multi_column_vertices(kind, renumber):
     assert max(abs(got[v] - want_p[v]) for v in want_p) < 1e-6
     with pytest.raises(ValueError, match="vertex not found"):
         cugraph.pagerank(G, personalization=bad)
+
+
+def test_adjacency_list_and_matrix_inputs():
+    """graph_classes.py:206-271 from_cudf_adjlist (CSR arrays), :443-500 from_pandas_adjacency /
+    from_numpy_array / from_numpy_matrix: the same ranks as the edge-list graph of the same edges."""
+    import scipy.sparse
+    from cugraph_amd import cugraph
+
+    pdf = _karate_frame()
+    base = cugraph.pagerank(_directed_graph(), max_iter=500, tol=1e-7)
+    want = dict(zip(base["vertex"].tolist(), base["pagerank"].tolist()))
+    M = scipy.sparse.coo_matrix((pdf["weights"], (pdf["src"], pdf["dst"])), shape=(34, 34)).tocsr()
+    G = cugraph.Graph(directed=True)
+    G.from_cudf_adjlist(pd.Series(M.indptr), pd.Series(M.indices), pd.Series(M.data), store_transposed=True)
+    assert G.number_of_vertices() == 34 and G.number_of_edges() == 156
+    df = cugraph.pagerank(G, max_iter=500, tol=1e-7)
+    got = dict(zip(df["vertex"].tolist(), df["pagerank"].tolist()))
+    assert max(abs(got[v] - want[v]) for v in want) < 1e-7
+    with pytest.raises(RuntimeError, match="already has values"):
+        G.from_cudf_adjlist(pd.Series(M.indptr), pd.Series(M.indices))
+    with pytest.raises(ValueError):
+        cugraph.Graph(directed=True).from_cudf_adjlist(pd.Series([0, 2, 1]), pd.Series([0, 1]))
+    # an undirected graph stores both directions itself; a vertex without edges (33 rows + 1) still counts
+    U = cugraph.Graph()
+    sym = (M + M.T).tocsr()
+    sym.resize((35, 35))
+    U.from_cudf_adjlist(pd.Series(sym.indptr), pd.Series(sym.indices), store_transposed=True)
+    assert U.number_of_vertices() == 35
+    udf = cugraph.pagerank(U, max_iter=500, tol=1e-7)
+    nxU = nx.Graph()
+    nxU.add_nodes_from(range(35))
+    nxU.add_edges_from(zip(pdf["src"].tolist(), pdf["dst"].tolist()))
+    uw = nx.pagerank(nxU, alpha=0.85, tol=1e-9, max_iter=500)
+    ug = dict(zip(udf["vertex"].tolist(), udf["pagerank"].tolist()))
+    assert set(ug) == set(uw) and max(abs(ug[v] - uw[v]) for v in uw) < 1e-6
+    # dense adjacency with labelled nodes
+    A = np.zeros((34, 34))
+    A[pdf["src"], pdf["dst"]] = pdf["weights"]
+    labels = [f"n{v:02d}" for v in range(34)]
+    D = cugraph.Graph(directed=True)
+    D.from_pandas_adjacency(pd.DataFrame(A, columns=labels))
+    with pytest.warns(UserWarning, match="store_transposed"):
+        ddf = cugraph.pagerank(D, max_iter=500, tol=1e-7)
+    dg = {int(k[1:]): v for k, v in zip(ddf["vertex"].tolist(), ddf["pagerank"].tolist())}
+    assert max(abs(dg[v] - want[v]) for v in want) < 1e-6
+    N = cugraph.Graph(directed=True)
+    N.from_numpy_matrix(np.matrix(A))
+    assert N.number_of_edges() == 156
+    with pytest.raises(TypeError):
+        cugraph.Graph().from_numpy_matrix(A)
+    with pytest.raises(ValueError):
+        cugraph.Graph().from_numpy_array(np.zeros(3))
