@@ -93,6 +93,72 @@ class Graph:
         loops = int((df["src"] == df["dst"]).sum())
         return (n - loops) // 2 + loops
 
+    def _external(self, ids, column_name):
+        """frame of the caller's vertex names for internal ids (one or several columns)"""
+        import pandas as pd
+
+        if self.renumber_map is None:
+            return pd.DataFrame({column_name: np.asarray(ids)})
+        return self.renumber_map.from_internal(ids, column_name)
+
+    def view_edge_list(self):
+        """simpleGraph.py:630-700: the edge list in the caller's vertex names -- `src`, `dst`
+        (`0_src`, ... for multi-column vertices) and `weights`; one row per undirected edge"""
+        import pandas as pd
+
+        df = self.edgelist.edgelist_df
+        if not self.is_directed():
+            df = df[df["src"] <= df["dst"]].reset_index(drop=True)
+        out = pd.concat([self._external(df["src"].to_numpy(), "src"), self._external(df["dst"].to_numpy(), "dst")],
+                        axis=1)
+        if self.edgelist.weights:
+            out["weights"] = df["weights"].to_numpy()
+        return out
+
+    def nodes(self):
+        """simpleGraph.py:1020-1050: the vertices that occur in the edge list (plus the vertex list, if given)"""
+        df = self.edgelist.edgelist_df
+        ids = np.union1d(df["src"].to_numpy(), df["dst"].to_numpy())
+        if self._vertices is not None:
+            ids = np.union1d(ids, self._vertices)
+        out = self._external(ids, "vertex")
+        return out["vertex"] if out.shape[1] == 1 else out
+
+    def _degrees(self):
+        df = self.edgelist.edgelist_df
+        ids = self.nodes() if self.renumber_map is None else None
+        verts = np.asarray(ids) if ids is not None else np.arange(len(self.renumber_map.table))
+        pos = {int(v): i for i, v in enumerate(verts.tolist())}
+        ind, outd = np.zeros(len(verts), np.int64), np.zeros(len(verts), np.int64)
+        np.add.at(outd, [pos[int(v)] for v in df["src"].tolist()], 1)
+        np.add.at(ind, [pos[int(v)] for v in df["dst"].tolist()], 1)
+        return verts, ind, outd
+
+    def in_degree(self):
+        """frame `vertex`, `degree` (simpleGraph.py:780-830); an undirected edge counts once per end"""
+        verts, ind, _ = self._degrees()
+        out = self._external(verts, "vertex")
+        out["degree"] = ind
+        return out
+
+    def out_degree(self):
+        verts, _, outd = self._degrees()
+        out = self._external(verts, "vertex")
+        out["degree"] = outd
+        return out
+
+    def degree(self):
+        """in + out for a directed graph, the number of incident edges for an undirected one"""
+        verts, ind, outd = self._degrees()
+        out = self._external(verts, "vertex")
+        out["degree"] = ind + outd if self.is_directed() else outd
+        return out
+
+    def has_isolated_vertices(self):
+        """graph_classes.py:669-686: vertices (of the vertex list) that no edge touches"""
+        _, ind, outd = self._degrees()
+        return bool(np.any((ind + outd) == 0))
+
     # ------------------------------------------------------------------ intake
     def from_pandas_edgelist(self, pdf, source="source", destination="destination", edge_attr=None,
                              weight=None, renumber=True, store_transposed=False,

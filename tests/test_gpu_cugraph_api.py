@@ -328,3 +328,28 @@ def test_adjacency_list_and_matrix_inputs():
         cugraph.Graph().from_numpy_matrix(A)
     with pytest.raises(ValueError):
         cugraph.Graph().from_numpy_array(np.zeros(3))
+
+
+def test_graph_queries():
+    """view_edge_list / nodes / degrees / has_isolated_vertices in the caller's vertex names"""
+    from cugraph_amd import cugraph
+
+    pdf = _karate_frame()
+    G = _directed_graph()
+    el = G.view_edge_list()
+    assert sorted(zip(el["src"], el["dst"])) == sorted(zip(pdf["src"], pdf["dst"])) and "weights" in el
+    assert sorted(G.nodes().tolist()) == list(range(34)) and not G.has_isolated_vertices()
+    ind = dict(zip(G.in_degree()["vertex"], G.in_degree()["degree"]))
+    assert all(ind[v] == int((pdf["dst"] == v).sum()) for v in range(34))
+    deg = dict(zip(G.degree()["vertex"], G.degree()["degree"]))
+    assert all(deg[v] == int((pdf["dst"] == v).sum() + (pdf["src"] == v).sum()) for v in range(34))
+    U = cugraph.Graph()
+    U.from_pandas_edgelist(pd.DataFrame({"a": ["x", "y", "z"], "b": ["y", "z", "x"]}), "a", "b",
+                           vertices=["x", "y", "z", "lonely"])
+    assert sorted(U.nodes().tolist()) == ["lonely", "x", "y", "z"] and U.has_isolated_vertices()
+    assert len(U.view_edge_list()) == 3 and U.number_of_edges() == 3
+    d = dict(zip(U.degree()["vertex"], U.degree()["degree"]))
+    assert d == {"x": 2, "y": 2, "z": 2, "lonely": 0}
+    df = cugraph.pagerank(U, max_iter=500, tol=1e-9)
+    pr = dict(zip(df["vertex"], df["pagerank"]))
+    assert abs(pr["x"] - pr["y"]) < 1e-7 and pr["lonely"] < pr["x"] and abs(sum(pr.values()) - 1) < 1e-6
