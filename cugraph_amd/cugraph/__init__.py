@@ -7,6 +7,8 @@ the result frame is a pandas DataFrame; the device work is the same pylibcugraph
 from . import exceptions
 from .exceptions import FailedToConvergeError
 from .graph import Graph, MultiGraph
+from .centrality import eigenvector_centrality, hits, katz_centrality
 from .link_analysis import nx_pagerank, pagerank
 
-__all__ = ["Graph", "MultiGraph", "pagerank", "nx_pagerank", "FailedToConvergeError", "exceptions"]
+__all__ = ["Graph", "MultiGraph", "pagerank", "nx_pagerank", "katz_centrality", "eigenvector_centrality", "hits",
+           "FailedToConvergeError", "exceptions"]

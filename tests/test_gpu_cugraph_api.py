@@ -353,3 +353,51 @@ def test_graph_queries():
     df = cugraph.pagerank(U, max_iter=500, tol=1e-9)
     pr = dict(zip(df["vertex"], df["pagerank"]))
     assert abs(pr["x"] - pr["y"]) < 1e-7 and pr["lonely"] < pr["x"] and abs(sum(pr.values()) - 1) < 1e-6
+
+
+def test_sibling_centralities_at_the_frame_level():
+    """cugraph.katz_centrality / eigenvector_centrality / hits (katz_centrality.py:30-205,
+    eigenvector_centrality.py:27-140, hits.py:28-140) against NetworkX on karate, with string
+    vertex names, NetworkX input, and the reference's argument checks."""
+    from cugraph_amd import cugraph
+
+    pdf = _karate_frame()
+    name = lambda v: f"m{v:02d}"  # noqa: E731
+    frame = pd.DataFrame({"a": [name(v) for v in pdf["src"]], "b": [name(v) for v in pdf["dst"]]})
+    G = cugraph.Graph(directed=True)
+    G.from_cudf_edgelist(frame, source="a", destination="b", store_transposed=True)
+    nxG = nx.DiGraph()
+    nxG.add_edges_from(zip(frame["a"], frame["b"]))
+    alpha = 1 / max(d for _, d in nxG.degree())
+    kz = cugraph.katz_centrality(G, max_iter=1000, tol=1e-9)
+    assert list(kz.columns) == ["vertex", "katz_centrality"]
+    want = nx.katz_centrality(nxG, alpha=alpha, beta=1.0, max_iter=1000, tol=1e-9, normalized=False)
+    got = dict(zip(kz["vertex"], kz["katz_centrality"]))
+    scale = np.linalg.norm(list(want.values())) if abs(np.linalg.norm(list(got.values())) - 1) < 1e-3 else 1.0
+    assert max(abs(got[v] - want[v] / scale) for v in want) < 1e-5
+    ev = cugraph.eigenvector_centrality(G, max_iter=1000, tol=1e-7)  # (an unweighted graph computes in fp32)
+    want = nx.eigenvector_centrality(nxG, max_iter=2000, tol=1e-12)
+    got = dict(zip(ev["vertex"], ev["eigenvector_centrality"]))
+    assert max(abs(got[v] - want[v]) for v in want) < 1e-4
+    ht = cugraph.hits(G, max_iter=1000, tol=1e-7)
+    wh, wa = nx.hits(nxG, max_iter=2000, tol=1e-12, normalized=True)
+    assert list(ht.columns) == ["vertex", "hubs", "authorities"]
+    gh, ga = dict(zip(ht["vertex"], ht["hubs"])), dict(zip(ht["vertex"], ht["authorities"]))
+    assert max(abs(gh[v] - wh[v]) for v in wh) < 1e-5 and max(abs(ga[v] - wa[v]) for v in wa) < 1e-5
+    nstart = pd.DataFrame({"vertex": [name(v) for v in range(34)], "values": np.full(34, 1 / 34, np.float32)})
+    ht2 = cugraph.hits(G, max_iter=1000, tol=1e-7, nstart=nstart)
+    assert max(abs(a - b) for a, b in zip(sorted(ht2["hubs"]), sorted(ht["hubs"]))) < 1e-6
+    # NetworkX graph in, dicts out
+    h2, a2 = cugraph.hits(nxG, max_iter=1000, tol=1e-7)
+    assert max(abs(h2[v] - wh[v]) for v in wh) < 1e-5 and set(a2) == set(wa)
+    assert set(cugraph.eigenvector_centrality(nxG)) == set(nxG.nodes())
+    with pytest.raises(ValueError, match="'alpha' must be a positive float"):
+        cugraph.katz_centrality(G, alpha=-1.0)
+    with pytest.raises(ValueError, match="'max_iter' must be a positive integer"):
+        cugraph.eigenvector_centrality(G, max_iter=0)
+    with pytest.raises(ValueError, match="'tol' must be a positive float"):
+        cugraph.katz_centrality(G, tol=0)
+    T = cugraph.Graph(directed=True)
+    T.from_cudf_edgelist(frame, source="a", destination="b", store_transposed=False)
+    with pytest.warns(UserWarning, match="HITS expects the 'store_transposed' flag"):
+        cugraph.hits(T)
