@@ -137,6 +137,10 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// rows of in-degree 1 .. kLowDegreeMax are the thread-per-row bucket of the pull SpMV (pagerank.hip)
+// and the classes the renumbering orders by their smallest source (renumber.hip)
+constexpr int kLowDegreeMax = 3;
+
 // position of `id` in an ascending array of distinct ids, -1 if absent
 __host__ __device__ inline int64_t find_sorted(long long const* sorted, int64_t n, long long id)
 {

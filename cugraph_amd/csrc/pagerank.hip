@@ -53,7 +53,7 @@ constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longe
 // whose entry format still covers the source space with the windows a record carries
 constexpr int kXsRowBits      = 12;
 constexpr int kXsRowBitsMax   = 14;
-constexpr int kXsMinDegree    = 4;
+constexpr int kXsMinDegree    = kLowDegreeMax + 1;
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
 // a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile

@@ -169,19 +169,17 @@ __global__ void compact_tally_kernel(unsigned int const* __restrict__ tally, uns
   }
 }
 
-// vertices of degree >= 4, >= 3, >= 2, >= 1
+// out[k] = vertices of degree >= kLowDegreeMax + 1 - k, k = 0 .. kLowDegreeMax
 __global__ void count_degree_classes_kernel(unsigned int const* __restrict__ deg, int64_t n, unsigned long long* out)
 {
-  unsigned long long c[4] = {0, 0, 0, 0};
+  unsigned long long c[kLowDegreeMax + 1] = {};
   GRID_STRIDE(i, n)
   {
     unsigned int const d = deg[i];
-    c[0] += d >= 4;
-    c[1] += d >= 3;
-    c[2] += d >= 2;
-    c[3] += d >= 1;
+#pragma unroll
+    for (int k = 0; k <= kLowDegreeMax; ++k) c[k] += d >= static_cast<unsigned int>(kLowDegreeMax + 1 - k);
   }
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k <= kLowDegreeMax; ++k) {
     for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o, 64);
     if ((threadIdx.x & 63) == 0 && c[k]) atomicAdd(&out[k], c[k]);
   }
@@ -889,14 +887,14 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
   char const* loc_env = std::getenv("CUGRAPH_AMD_RENUMBER_LOCALITY");
   bool const locality = loc_env ? loc_env[0] == '1' : ne >= (int64_t{1} << 22);
   if (majors_are_dst && locality && nv > 0 && ne > 0) {
-    DevBuf n_ge(4 * sizeof(unsigned long long));
+    DevBuf n_ge((kLowDegreeMax + 1) * sizeof(unsigned long long));
     CGA_HIP(hipMemsetAsync(n_ge.p, 0, n_ge.bytes, stream));
     hipLaunchKernelGGL(count_degree_classes_kernel, dim3(grid_for(nv, 1024)), dim3(kThreads), 0, stream,
                        deg.as<unsigned int>(), nv, n_ge.as<unsigned long long>());
-    unsigned long long h_ge[4];  // vertices of degree >= 4, >= 3, >= 2, >= 1
+    unsigned long long h_ge[kLowDegreeMax + 1];  // vertices of degree >= kLowDegreeMax + 1, ..., >= 2, >= 1
     CGA_HIP(hipMemcpyAsync(h_ge, n_ge.p, sizeof(h_ge), hipMemcpyDeviceToHost, stream));
     CGA_HIP(hipStreamSynchronize(stream));
-    int64_t const first = static_cast<int64_t>(h_ge[0]), n_low = static_cast<int64_t>(h_ge[3]) - first;
+    int64_t const first = static_cast<int64_t>(h_ge[0]), n_low = static_cast<int64_t>(h_ge[kLowDegreeMax]) - first;
     if (n_low > 1) {
       DevBuf minsrc(static_cast<size_t>(n_low) * 4), remap(static_cast<size_t>(n_low) * 4);
       CGA_HIP(hipMemsetAsync(minsrc.p, 0xff, minsrc.bytes, stream));
@@ -909,7 +907,7 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
       CGA_HIP(hipMemcpyAsync(old_order.p, order.as<int32_t>() + first, static_cast<size_t>(n_low) * 4,
                              hipMemcpyDeviceToDevice, stream));
       hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_low)), dim3(kThreads), 0, stream, remap.as<int32_t>(), n_low);
-      for (int c = 0; c < 3; ++c) {  // degree 3, 2, 1
+      for (int c = 0; c < kLowDegreeMax; ++c) {  // degree kLowDegreeMax, ..., 2, 1
         int64_t const a = static_cast<int64_t>(h_ge[c]) - first, b = static_cast<int64_t>(h_ge[c + 1]) - first;
         if (b - a < 2) continue;
         DevBuf sub_order, sub_rank;
