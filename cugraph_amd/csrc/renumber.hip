@@ -552,6 +552,64 @@ bool degrees_descending(hipStream_t stream, void const* offsets, bool off64, int
   return h_up == 0;
 }
 
+// Locality of the low-degree rows: a pull iteration gives the rows of degree 1 .. kLowDegreeMax one
+// thread each, and consecutive threads gather from wherever their rows' sources are.  The order
+// among rows of EQUAL degree is free (the reference's is whatever its sort leaves), so inside each
+// of those classes the rows are put in the order of their smallest source: neighbouring threads
+// then read neighbouring slots of the gathered vector (scale 26: 0.31 -> 0.22 ms for those rows).
+// Works on the relabelled endpoints (a row's class follows from its new id) and updates them, the
+// order and the rank in place; true when anything moved.  deg: degrees by the labels `order` maps to.
+// CUGRAPH_AMD_RENUMBER_LOCALITY=0 / 1: never / also on small graphs (tests); by default from 4 M
+// edges.  (Ids that go through the hash-set path keep the plain order.)
+bool refine_low_degree_order(hipStream_t stream, unsigned int const* deg, int64_t nv, int64_t ne,
+                             int32_t* majors, int32_t* minors, DevBuf& order, DevBuf& rank)
+{
+  char const* loc_env = std::getenv("CUGRAPH_AMD_RENUMBER_LOCALITY");
+  bool const locality = loc_env ? loc_env[0] == '1' : ne >= (int64_t{1} << 22);
+  if (!locality || nv <= 0 || ne <= 0) return false;
+  DevBuf n_ge((kLowDegreeMax + 1) * sizeof(unsigned long long));
+  CGA_HIP(hipMemsetAsync(n_ge.p, 0, n_ge.bytes, stream));
+  hipLaunchKernelGGL(count_degree_classes_kernel, dim3(grid_for(nv, 1024)), dim3(kThreads), 0, stream, deg, nv,
+                     n_ge.as<unsigned long long>());
+  unsigned long long h_ge[kLowDegreeMax + 1];  // vertices of degree >= kLowDegreeMax + 1, ..., >= 2, >= 1
+  CGA_HIP(hipMemcpyAsync(h_ge, n_ge.p, sizeof(h_ge), hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  int64_t const first = static_cast<int64_t>(h_ge[0]), n_low = static_cast<int64_t>(h_ge[kLowDegreeMax]) - first;
+  if (n_low < 2) return false;
+  DevBuf minsrc(static_cast<size_t>(n_low) * 4), remap(static_cast<size_t>(n_low) * 4);
+  CGA_HIP(hipMemsetAsync(minsrc.p, 0xff, minsrc.bytes, stream));
+  hipLaunchKernelGGL(low_min_source_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, majors, minors, ne,
+                     first, n_low, minsrc.as<unsigned int>());
+  // descending sort of (nv - 1 - smallest source) = ascending smallest source, class by class
+  hipLaunchKernelGGL(flip_keys_kernel, dim3(grid_for(n_low)), dim3(kThreads), 0, stream,
+                     minsrc.as<unsigned int>(), n_low, static_cast<unsigned int>(nv - 1));
+  DevBuf old_order(static_cast<size_t>(n_low) * 4);
+  CGA_HIP(hipMemcpyAsync(old_order.p, order.as<int32_t>() + first, static_cast<size_t>(n_low) * 4,
+                         hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_low)), dim3(kThreads), 0, stream, remap.as<int32_t>(), n_low);
+  for (int c = 0; c < kLowDegreeMax; ++c) {  // degree kLowDegreeMax, ..., 2, 1
+    int64_t const a = static_cast<int64_t>(h_ge[c]) - first, b = static_cast<int64_t>(h_ge[c + 1]) - first;
+    if (b - a < 2) continue;
+    DevBuf sub_order, sub_rank;
+    degree_order(stream, minsrc.as<unsigned int>() + a, b - a, sub_order, sub_rank);
+    hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(b - a)), dim3(kThreads), 0, stream,
+                       old_order.as<int32_t>() + a, sub_order.as<int32_t>(), b - a,
+                       order.as<int32_t>() + first + a);
+    hipLaunchKernelGGL(offset_i32_kernel, dim3(grid_for(b - a)), dim3(kThreads), 0, stream,
+                       sub_rank.as<int32_t>(), b - a, static_cast<int32_t>(a), remap.as<int32_t>() + a);
+    CGA_HIP(hipStreamSynchronize(stream));  // sub_order / sub_rank die here
+  }
+  hipLaunchKernelGGL(remap_low_ids_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, minors, ne,
+                     static_cast<int32_t>(first), static_cast<unsigned int>(n_low), remap.as<int32_t>());
+  hipLaunchKernelGGL(remap_low_ids_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, majors, ne,
+                     static_cast<int32_t>(first), static_cast<unsigned int>(n_low), remap.as<int32_t>());
+  hipLaunchKernelGGL(invert_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, order.as<int32_t>(), nv,
+                     rank.as<int32_t>());
+  CGA_HIP(hipGetLastError());
+  CGA_HIP(hipStreamSynchronize(stream));  // minsrc / remap / old_order die here
+  return true;
+}
+
 // A degree-sorted copy of a compressed graph whose ids are 0..V-1 (the pull plan of graphs built
 // with renumber=FALSE).  number_map (int32) and ext_lookup describe the permutation.
 Graph* degree_sorted_copy(Handle const& h, Graph const& g)
@@ -571,15 +629,23 @@ Graph* degree_sorted_copy(Handle const& h, Graph const& g)
   }
   DevBuf order, rank;
   degree_order_sources_first(stream, deg.as<unsigned int>(), g.indices, ne, n, order, rank);
-  deg.release();
   DevBuf majors(static_cast<size_t>(ne > 0 ? ne : 1) * 4), minors(static_cast<size_t>(ne > 0 ? ne : 1) * 4);
   expand_offsets(stream, g.offsets, g.off64, n, ne, majors.as<int32_t>());
   if (ne > 0)
     CGA_HIP(hipMemcpyAsync(minors.p, g.indices, static_cast<size_t>(ne) * 4, hipMemcpyDeviceToDevice, stream));
   relabel_ids(stream, majors.as<int32_t>(), ne, rank.as<int32_t>());
   relabel_ids(stream, minors.as<int32_t>(), ne, rank.as<int32_t>());
+  if (g.store_transposed)
+    refine_low_degree_order(stream, deg.as<unsigned int>(), n, ne, majors.as<int32_t>(), minors.as<int32_t>(), order,
+                            rank);
+  DevBuf counts(static_cast<size_t>(n > 0 ? n : 1) * 4);
+  if (n > 0)
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, deg.as<unsigned int>(),
+                       order.as<int32_t>(), n, counts.as<unsigned int>());
+  deg.release();
   CompressedOut out = compress_coo(stream, n, n, ne, majors.as<int32_t>(), minors.as<int32_t>(),
-                                   g.weights, g.weights ? dtype_size(g.weight_type) : 0);
+                                   g.weights, g.weights ? dtype_size(g.weight_type) : 0,
+                                   counts.as<unsigned int>(), true);
   auto ig                 = std::make_unique<Graph>();
   ig->vertex_type         = INT32;
   ig->edge_type           = g.edge_type;
@@ -876,66 +942,17 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
   };
   relabel(src, src32);
   relabel(dst, dst32);
-  // ---- locality of the low-degree rows: a pull iteration gives the rows of degree 1-3 one thread
-  // each, and consecutive threads gather from wherever their rows' sources are.  The order among
-  // rows of EQUAL degree is free (the reference's is whatever its sort leaves), so inside each of
-  // those three classes the rows are put in the order of their smallest source: neighbouring
-  // threads then read neighbouring slots of the gathered vector (scale 26: 0.31 -> 0.22 ms for
-  // those rows).  Done on the relabelled endpoints: a row's class follows from its new id.
-  // (CUGRAPH_AMD_RENUMBER_LOCALITY=0 / 1: never / also on small graphs, for tests; ids that go
-  // through the hash-set path keep the plain order)
-  char const* loc_env = std::getenv("CUGRAPH_AMD_RENUMBER_LOCALITY");
-  bool const locality = loc_env ? loc_env[0] == '1' : ne >= (int64_t{1} << 22);
-  if (majors_are_dst && locality && nv > 0 && ne > 0) {
-    DevBuf n_ge((kLowDegreeMax + 1) * sizeof(unsigned long long));
-    CGA_HIP(hipMemsetAsync(n_ge.p, 0, n_ge.bytes, stream));
-    hipLaunchKernelGGL(count_degree_classes_kernel, dim3(grid_for(nv, 1024)), dim3(kThreads), 0, stream,
-                       deg.as<unsigned int>(), nv, n_ge.as<unsigned long long>());
-    unsigned long long h_ge[kLowDegreeMax + 1];  // vertices of degree >= kLowDegreeMax + 1, ..., >= 2, >= 1
-    CGA_HIP(hipMemcpyAsync(h_ge, n_ge.p, sizeof(h_ge), hipMemcpyDeviceToHost, stream));
-    CGA_HIP(hipStreamSynchronize(stream));
-    int64_t const first = static_cast<int64_t>(h_ge[0]), n_low = static_cast<int64_t>(h_ge[kLowDegreeMax]) - first;
-    if (n_low > 1) {
-      DevBuf minsrc(static_cast<size_t>(n_low) * 4), remap(static_cast<size_t>(n_low) * 4);
-      CGA_HIP(hipMemsetAsync(minsrc.p, 0xff, minsrc.bytes, stream));
-      hipLaunchKernelGGL(low_min_source_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, dst32, src32, ne,
-                         first, n_low, minsrc.as<unsigned int>());
-      // descending sort of (nv - 1 - smallest source) = ascending smallest source, class by class
-      hipLaunchKernelGGL(flip_keys_kernel, dim3(grid_for(n_low)), dim3(kThreads), 0, stream,
-                         minsrc.as<unsigned int>(), n_low, static_cast<unsigned int>(nv - 1));
-      DevBuf old_order(static_cast<size_t>(n_low) * 4);
-      CGA_HIP(hipMemcpyAsync(old_order.p, order.as<int32_t>() + first, static_cast<size_t>(n_low) * 4,
-                             hipMemcpyDeviceToDevice, stream));
-      hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_low)), dim3(kThreads), 0, stream, remap.as<int32_t>(), n_low);
-      for (int c = 0; c < kLowDegreeMax; ++c) {  // degree kLowDegreeMax, ..., 2, 1
-        int64_t const a = static_cast<int64_t>(h_ge[c]) - first, b = static_cast<int64_t>(h_ge[c + 1]) - first;
-        if (b - a < 2) continue;
-        DevBuf sub_order, sub_rank;
-        degree_order(stream, minsrc.as<unsigned int>() + a, b - a, sub_order, sub_rank);
-        hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(b - a)), dim3(kThreads), 0, stream,
-                           old_order.as<int32_t>() + a, sub_order.as<int32_t>(), b - a,
-                           order.as<int32_t>() + first + a);
-        hipLaunchKernelGGL(offset_i32_kernel, dim3(grid_for(b - a)), dim3(kThreads), 0, stream,
-                           sub_rank.as<int32_t>(), b - a, static_cast<int32_t>(a), remap.as<int32_t>() + a);
-        CGA_HIP(hipStreamSynchronize(stream));  // sub_order / sub_rank die here
-      }
-      hipLaunchKernelGGL(remap_low_ids_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, src32, ne,
-                         static_cast<int32_t>(first), static_cast<unsigned int>(n_low), remap.as<int32_t>());
-      hipLaunchKernelGGL(remap_low_ids_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, stream, dst32, ne,
-                         static_cast<int32_t>(first), static_cast<unsigned int>(n_low), remap.as<int32_t>());
-      hipLaunchKernelGGL(invert_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, stream, order.as<int32_t>(), nv,
-                         rank.as<int32_t>());
-      if (wide)
-        hipLaunchKernelGGL((number_map_kernel<int64_t>), dim3(grid_for(range)), dim3(kThreads), 0, stream,
-                           range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
-                           nmap.as<int64_t>(), lookup.as<int32_t>());
-      else
-        hipLaunchKernelGGL((number_map_kernel<int32_t>), dim3(grid_for(range)), dim3(kThreads), 0, stream,
-                           range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
-                           nmap.as<int32_t>(), lookup.as<int32_t>());
-      CGA_HIP(hipGetLastError());
-      CGA_HIP(hipStreamSynchronize(stream));  // minsrc / remap / old_order die here
-    }
+  // ---- locality of the low-degree rows (refine_low_degree_order)
+  if (majors_are_dst && refine_low_degree_order(stream, deg.as<unsigned int>(), nv, ne, dst32, src32, order, rank)) {
+    if (wide)
+      hipLaunchKernelGGL((number_map_kernel<int64_t>), dim3(grid_for(range)), dim3(kThreads), 0, stream,
+                         range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
+                         nmap.as<int64_t>(), lookup.as<int32_t>());
+    else
+      hipLaunchKernelGGL((number_map_kernel<int32_t>), dim3(grid_for(range)), dim3(kThreads), 0, stream,
+                         range, lo, flags.as<unsigned int>(), pos.as<int64_t>(), rank.as<int32_t>(),
+                         nmap.as<int32_t>(), lookup.as<int32_t>());
+    CGA_HIP(hipGetLastError());
   }
   if (major_counts_out && nv > 0) {  // the degrees in the new order: the build's histogram, for free
     major_counts_out->alloc(static_cast<size_t>(nv) * 4);
