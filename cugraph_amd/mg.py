@@ -38,6 +38,7 @@ The local compute is reached through an *engine* object so that the driver logic
 routing, collectives, stop rule, result assembly) can be exercised at world_size 2 on CPU with
 a test double; the product engine is `HipEngine` and there is no other in this package.
 """
+import os
 import time
 
 import numpy as np
@@ -240,32 +241,51 @@ class MGPagerank:
                 dist.all_reduce(sums, group=group)
         # rows: descending in-degree inside the owned range
         self.order, self.rank_local = engine.degree_order(dst, self.first, self.last)
-        order = self.order.long()
-        # slots: this rank's vertices with out-edges, numbered in row order
-        active = counts[self.first:self.last][order] > 0
-        n_active = torch.count_nonzero(active).reshape(1).to(torch.int64)
+        own_counts = counts[self.first:self.last]
+
+        def assign_slots():
+            """slots: this rank's vertices with out-edges, numbered in row order (hottest first);
+            returns x_pos (row -> slot or -1), the caller's id -> slot table of every rank's range
+            (one all-gather of the per-rank tables), the slot count and the hot slots"""
+            order = self.order.long()
+            active = own_counts[order] > 0
+            n_active = torch.count_nonzero(active).reshape(1).to(torch.int64)
+            if world > 1:
+                dist.all_reduce(n_active, op=dist.ReduceOp.MAX, group=group)
+            self.slot_chunk = max(int(n_active.item()), 1)
+            self.regions = self._choose_regions(engine, self.slot_chunk, world)
+            j = torch.cumsum(active, 0) - 1  # index of a row among this rank's sources
+            if self.regions is None:
+                slot = j + rank * self.slot_chunk
+                n_slots, hot_slots = self.slot_chunk * world, 0
+            else:
+                c0, c1 = self.regions
+                slot = torch.where(j < c0, j + rank * c0, j - c0 + world * c0 + rank * c1)
+                n_slots, hot_slots = world * (c0 + c1), world * c0
+            x_pos = torch.where(active, slot, torch.full_like(order, -1)).to(torch.int32)
+            slot_of = torch.full((self.chunk * world,), -1, dtype=torch.int32, device=src.device)
+            slot_of[self.first + order] = x_pos
+            if world > 1:
+                all_gather_in_place(slot_of, self.chunk, rank, world, group)
+            return x_pos, slot_of, n_slots, hot_slots
+
+        x_pos, slot_of, n_slots, hot_slots = assign_slots()
+        # rows of in-degree 1-3 in the order of their smallest source (decided for all ranks alike:
+        # the slots are assigned again afterwards, which is a collective)
+        n_edges_all = torch.tensor([src.numel()], dtype=torch.int64, device=src.device)
         if world > 1:
-            dist.all_reduce(n_active, op=dist.ReduceOp.MAX, group=group)
-        self.slot_chunk = max(int(n_active.item()), 1)
-        self.regions = self._choose_regions(engine, self.slot_chunk, world)
-        j = torch.cumsum(active, 0) - 1  # index of a row among this rank's sources (row order = hottest first)
-        if self.regions is None:
-            slot = j + rank * self.slot_chunk
-            n_slots, hot_slots = self.slot_chunk * world, 0
-        else:
-            c0, c1 = self.regions
-            slot = torch.where(j < c0, j + rank * c0, j - c0 + world * c0 + rank * c1)
-            n_slots, hot_slots = world * (c0 + c1), world * c0
-        x_pos = torch.where(active, slot, torch.full_like(order, -1)).to(torch.int32)
-        del active, j, slot
-        # caller's id -> slot, for every rank's range: one all-gather of the per-rank tables
-        slot_of = torch.full((self.chunk * world,), -1, dtype=torch.int32, device=src.device)
-        slot_of[self.first + order] = x_pos
-        if world > 1:
-            all_gather_in_place(slot_of, self.chunk, rank, world, group)
+            dist.all_reduce(n_edges_all, group=group)
+        env = os.environ.get("CUGRAPH_AMD_RENUMBER_LOCALITY")
+        if env == "1" or (env is None and int(n_edges_all.item()) >= (1 << 22)):
+            rows = self.rank_local[(dst - self.first).long()].long()
+            self._order_low_degree_rows_by_source(slot_of[src.long()].long(), rows)
+            del rows, x_pos, slot_of
+            # slots follow the rows, so that a rank still writes its values in row order
+            x_pos, slot_of, n_slots, hot_slots = assign_slots()
         src = slot_of[src.long()].to(self.vertex_dtype)
         dst = (self.rank_local[(dst - self.first).long()] + self.first).to(self.vertex_dtype)
         del slot_of
+        order = self.order.long()
         self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last, self.num_vertices,
                                              num_source_slots=n_slots, x_pos=x_pos, hot_slots=hot_slots)
         del src, dst, wgt, x_pos
@@ -273,6 +293,39 @@ class MGPagerank:
         del sums, counts
         self.t_build = time.perf_counter() - t0
         return self
+
+    def _order_low_degree_rows_by_source(self, src_slots, rows):
+        """Rows of in-degree 1, 2 and 3 in the order of their smallest source slot, inside each of
+        the three classes (the single-GPU renumbering does the same, renumber.hip
+        refine_low_degree_order: the thread-per-row bucket then gathers from neighbouring slots).
+        Rows only change places inside their degree class, so the degree order stands.
+        src_slots / rows: (provisional) source slot and current row of every local edge.
+        Updates self.order / self.rank_local."""
+        import torch
+
+        n_local = self.last - self.first
+        if n_local == 0 or rows.numel() == 0:
+            return
+        deg = torch.bincount(rows, minlength=n_local)
+        low = (deg >= 1) & (deg <= 3)
+        idx = torch.nonzero(low).reshape(-1)
+        if idx.numel() < 2:
+            return
+        assert int(idx[-1] - idx[0]) + 1 == idx.numel(), "low-degree rows must be one run of the degree order"
+        big = torch.iinfo(torch.int64).max
+        minsrc = torch.full((n_local,), big, dtype=torch.int64, device=rows.device)
+        minsrc.scatter_reduce_(0, rows, src_slots, reduce="amin", include_self=True)
+        # rows are in descending degree order already: a stable sort of the low rows by
+        # (degree descending, smallest source ascending) only moves rows inside their class
+        key = (3 - deg[idx]) * (int(minsrc[idx].max()) + 1) + minsrc[idx]
+        perm = torch.argsort(key, stable=True)  # new position (inside the run) -> old position
+        first = int(idx[0])
+        order = self.order.clone()
+        order[first:first + perm.numel()] = self.order[first + perm]
+        self.order = order
+        rank_local = torch.empty_like(self.rank_local)
+        rank_local[order.long()] = torch.arange(n_local, dtype=self.rank_local.dtype, device=rows.device)
+        self.rank_local = rank_local
 
     @classmethod
     def from_rmat(cls, resource_handle, graph_properties, scale, num_edges, *, seed=42,

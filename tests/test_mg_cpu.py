@@ -33,6 +33,8 @@ def _worker(rank, world, port, case, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CUGRAPH_AMD_MG_REGIONS"] = case.get("regions", "auto")  # two regions of the gathered vector
+    # rows of in-degree 1-3 in the order of their smallest source slot (default: big graphs only)
+    os.environ["CUGRAPH_AMD_RENUMBER_LOCALITY"] = case.get("locality", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         src, dst, wgt, nv = case["src"], case["dst"], case["wgt"], case["nv"]
@@ -111,7 +113,7 @@ def _rmat_case(scale, weighted, **extra):
 def test_mg_matches_single_process_oracle(world, regions, want_regions, weighted, tmp_path):
     """regions: the gathered vector as two regions (hot slots first), two all-gathers per iteration and
     the iteration in two phases -- by default from 4 ranks (the stand-in's window is 48 slots)"""
-    case = _rmat_case(9, weighted, regions=regions, want_regions=want_regions)
+    case = _rmat_case(9, weighted, regions=regions, want_regions=want_regions, locality="1" if world >= 3 else "0")
     fulls, metas = _run(world, case, tmp_path)
     o_pr, o_it, o_conv = _oracle(case)
     for f, m in zip(fulls, metas):
@@ -130,7 +132,7 @@ def test_mg_personalization_nstart_and_nonconvergence(sharded, tmp_path):
     pers = (rng.permutation(nv)[:37].astype(np.int64), rng.random(37) + 0.1)  # un-normalised
     nstart = (rng.permutation(nv)[:300].astype(np.int64), rng.random(300))
     case = _rmat_case(9, True, pers=pers, nstart=nstart, max_iter=4, eps=1e-30, check=1, regions="1",
-                      want_regions=True, sharded=sharded)
+                      want_regions=True, sharded=sharded, locality="1")
     fulls, metas = _run(3 if sharded else 2, case, tmp_path)
     o_pr, o_it, o_conv = _oracle(case)
     assert o_it == 4 and not o_conv
