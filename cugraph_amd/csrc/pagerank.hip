@@ -1254,6 +1254,15 @@ __global__ void scale_kernel(ValT* p, int64_t n, double divisor)
 
 // dense personalization -> compact (vertex, p) list of the non-zero entries, ascending vertex
 template <typename ValT>
+__global__ void count_nonzero_kernel(ValT const* p, int64_t n, unsigned int* out)
+{
+  unsigned int c = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    c += p[i] != ValT(0) ? 1u : 0u;
+  if (c) atomicAdd(out, c);
+}
+
+template <typename ValT>
 __global__ void flag_nonzero_kernel(ValT const* dense, int64_t n, unsigned int* flags)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -1670,6 +1679,29 @@ __global__ void counts_to_sums_kernel(unsigned int* __restrict__ counts, int64_t
   }
 }
 
+// dead rows (no in-edges, no slot: no edge touches them): only if they are one run at the very end
+// (a degree-sorted graph built here has them there: renumber.hip, degree_order_sources_first; the
+// multi-GPU driver orders each rank's rows the same way).  g: a graph with x_pos.
+void detect_dead_rows(hipStream_t stream, Graph const& g, PullPlan& plan)
+{
+  char const* dead_env = std::getenv("CUGRAPH_AMD_DEAD_ROWS");
+  int64_t const n      = g.num_vertices;
+  if ((dead_env && dead_env[0] == '0') || !g.x_pos || n == 0) return;
+  DevBuf out(16);
+  unsigned long long h_out[2] = {0ull, ~0ull};
+  CGA_HIP(hipMemcpyAsync(out.p, h_out, 16, hipMemcpyHostToDevice, stream));
+  if (g.off64)
+    hipLaunchKernelGGL((dead_rows_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                       static_cast<int64_t const*>(g.offsets), g.x_pos, n, out.as<unsigned long long>());
+  else
+    hipLaunchKernelGGL((dead_rows_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
+                       static_cast<int32_t const*>(g.offsets), g.x_pos, n, out.as<unsigned long long>());
+  CGA_HIP(hipMemcpyAsync(h_out, out.p, 16, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  if (h_out[0] > 0 && h_out[1] + h_out[0] == static_cast<unsigned long long>(n))
+    plan.n_dead = static_cast<int64_t>(h_out[0]);
+}
+
 void build_compact(hipStream_t stream, Graph const& cg, PullPlan& plan)
 {
   char const* env = std::getenv("CUGRAPH_AMD_COMPACT");
@@ -1724,24 +1756,7 @@ void build_compact(hipStream_t stream, Graph const& cg, PullPlan& plan)
   c->x_pos               = static_cast<int32_t*>(x_pos.detach());
   c->num_source_slots    = std::max<int64_t>(n_slots, 1);
   plan.compact           = c.release();
-  // dead rows: only if they are one run at the very end (a degree-sorted graph built here has
-  // them there: renumber.hip, degree_order_sources_first)
-  char const* dead_env = std::getenv("CUGRAPH_AMD_DEAD_ROWS");
-  if (!(dead_env && dead_env[0] == '0')) {
-    DevBuf out(16);
-    unsigned long long h_out[2] = {0ull, ~0ull};
-    CGA_HIP(hipMemcpyAsync(out.p, h_out, 16, hipMemcpyHostToDevice, stream));
-    if (cg.off64)
-      hipLaunchKernelGGL((dead_rows_kernel<int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
-                         static_cast<int64_t const*>(cg.offsets), plan.compact->x_pos, n, out.as<unsigned long long>());
-    else
-      hipLaunchKernelGGL((dead_rows_kernel<int32_t>), dim3(grid_for(n)), dim3(kThreads), 0, stream,
-                         static_cast<int32_t const*>(cg.offsets), plan.compact->x_pos, n, out.as<unsigned long long>());
-    CGA_HIP(hipMemcpyAsync(h_out, out.p, 16, hipMemcpyDeviceToHost, stream));
-    CGA_HIP(hipStreamSynchronize(stream));
-    if (h_out[0] > 0 && h_out[1] + h_out[0] == static_cast<unsigned long long>(n))
-      plan.n_dead = static_cast<int64_t>(h_out[0]);
-  }
+  detect_dead_rows(stream, *plan.compact, plan);
 }
 
 PullPlan& get_plan(Handle const& h, Graph& g)
@@ -1764,6 +1779,7 @@ PullPlan& get_plan(Handle const& h, Graph& g)
       char const* xs_env = std::getenv("CUGRAPH_AMD_XS");
       bool want_xs = !(xs_env && xs_env[0] == '0') && p->contiguous;
       if (want_xs) build_compact(stream, vg, *p);
+      if (p->contiguous && vg.x_pos) detect_dead_rows(stream, vg, *p);  // the caller's slots (multi-GPU)
       Graph const& cg = p->compact ? *p->compact : vg;
       if (want_xs) {
         bool f64 = cg.weight_type == FLOAT64;
@@ -2132,9 +2148,18 @@ void session_setup(Session& s, PagerankArgs const& a)
   int n_prep_blocks = session_geometry<ValT>(s, plan);
   // a personalized run gives a dead row its own rank (teleport * p_v), and out-weight sums given
   // by the caller may call a dead row non-dangling: then they are all visited
-  s.n_dead = (!s.personalized && !a.pre_sums && plan.contiguous && plan.n_dead <= s.buckets[4].count)
-               ? plan.n_dead
-               : 0;
+  s.n_dead = (!s.personalized && plan.contiguous && plan.n_dead <= s.buckets[4].count) ? plan.n_dead : 0;
+  if (s.n_dead > 0 && a.pre_sums) {
+    // (the multi-GPU driver hands every rank the true sums: zero for a row no edge leaves)
+    DevBuf nz(4);
+    CGA_HIP(hipMemsetAsync(nz.p, 0, 4, stream));
+    hipLaunchKernelGGL((count_nonzero_kernel<ValT>), dim3(grid_for(s.n_dead)), dim3(kThreads), 0, stream,
+                       s.out_w.as<ValT>() + (nl - s.n_dead), s.n_dead, nz.as<unsigned int>());
+    unsigned int h_nz = 0;
+    CGA_HIP(hipMemcpyAsync(&h_nz, nz.p, 4, hipMemcpyDeviceToHost, stream));
+    CGA_HIP(hipStreamSynchronize(stream));
+    if (h_nz != 0) s.n_dead = 0;
+  }
 
   // ---- x0 and the dangling mass of pr0
   hipLaunchKernelGGL((prep_kernel<ValT>), dim3(n_prep_blocks), dim3(kThreads), 0, stream,

@@ -242,6 +242,7 @@ class MGPagerank:
         # rows: descending in-degree inside the owned range
         self.order, self.rank_local = engine.degree_order(dst, self.first, self.last)
         own_counts = counts[self.first:self.last]
+        self._sources_first_among_rows_without_in_edges(dst, own_counts)
 
         def assign_slots():
             """slots: this rank's vertices with out-edges, numbered in row order (hottest first);
@@ -293,6 +294,30 @@ class MGPagerank:
         del sums, counts
         self.t_build = time.perf_counter() - t0
         return self
+
+    def _sources_first_among_rows_without_in_edges(self, dst, own_counts):
+        """Among the rows without in-edges (the tail of the degree order), those some edge leaves
+        come first: what is left at the very end are the vertices no edge touches, which the
+        iteration does not visit (pagerank.hip: dead rows; renumber.hip does the same on one GPU).
+        Updates self.order / self.rank_local."""
+        import torch
+
+        n_local = self.last - self.first
+        if n_local == 0:
+            return
+        rows = self.rank_local[(dst - self.first).long()].long()
+        deg = torch.bincount(rows, minlength=n_local)
+        n_with = int(torch.count_nonzero(deg))
+        if n_local - n_with < 2:
+            return
+        tail = self.order[n_with:]
+        keep = torch.argsort((own_counts[tail.long()] == 0).to(torch.int8), stable=True)
+        order = self.order.clone()
+        order[n_with:] = tail[keep]
+        self.order = order
+        rank_local = torch.empty_like(self.rank_local)
+        rank_local[order.long()] = torch.arange(n_local, dtype=self.rank_local.dtype, device=order.device)
+        self.rank_local = rank_local
 
     def _order_low_degree_rows_by_source(self, src_slots, rows):
         """Rows of in-degree 1, 2 and 3 in the order of their smallest source slot, inside each of
