@@ -26,6 +26,10 @@ orders, actives = [], []
 for r in range(world):
     first, last, _ = mg.partition_bounds(nv, world, r)
     order = torch.sort(indeg[first:last], descending=True, stable=True).indices
+    # among the rows without in-edges, those some edge leaves first (the driver does the same: dead rows last)
+    n_with = int(torch.count_nonzero(indeg[first:last]))
+    tail = order[n_with:]
+    order = torch.cat([order[:n_with], tail[torch.argsort((outdeg[first:last][tail] == 0).to(torch.int8), stable=True)]])
     orders.append(order)
     actives.append(outdeg[first:last][order] > 0)
 slot_chunk = max(int(a.sum()) for a in actives)
@@ -57,6 +61,28 @@ s_l, d_l = torch.cat(parts_s), torch.cat(parts_d)
 del src, dst, sel, parts_s, parts_d
 rank_l = torch.empty_like(orders[me], dtype=torch.int32)
 rank_l[orders[me]] = torch.arange(last - first, dtype=torch.int32, device="cuda")
+if os.environ.get("CUGRAPH_AMD_RENUMBER_LOCALITY", "1") != "0":
+    # this rank's rows of in-degree 1-3 in the order of their smallest source slot; its slots follow its rows
+    # (mg.py: _order_low_degree_rows_by_source, then the slots are assigned again)
+    rows = rank_l[(d_l - first).long()].long()
+    deg = indeg[first:last][orders[me]].long()
+    idx = torch.nonzero((deg >= 1) & (deg <= 3)).reshape(-1)
+    minsrc = torch.full((last - first,), torch.iinfo(torch.int64).max, dtype=torch.int64, device="cuda")
+    minsrc.scatter_reduce_(0, rows, slot_of[s_l.long()].long(), reduce="amin", include_self=True)
+    key = (3 - deg[idx]) * (int(minsrc[idx].max()) + 1) + minsrc[idx]
+    perm = torch.argsort(key, stable=True)
+    f0 = int(idx[0])
+    new_order = orders[me].clone()
+    new_order[f0:f0 + perm.numel()] = orders[me][f0 + perm]
+    orders[me] = new_order
+    rank_l[new_order] = torch.arange(last - first, dtype=torch.int32, device="cuda")
+    a = outdeg[first:last][new_order] > 0
+    j = torch.cumsum(a, 0) - 1
+    slot = j + me * slot_chunk if regions is None else torch.where(j < regions[0], j + me * regions[0],
+                                                                    j - regions[0] + hot + me * regions[1])
+    my_x_pos = torch.where(a, slot, torch.full_like(new_order, -1)).to(torch.int32)
+    slot_of[first + new_order] = my_x_pos
+    del rows, deg, idx, minsrc, key, perm
 g = eng.make_local_graph(slot_of[s_l.long()], rank_l[(d_l - first).long()] + first, None, first, last, nv,
                          num_source_slots=n_slots, x_pos=my_x_pos, hot_slots=hot)
 n_local_edges = int(s_l.numel())
