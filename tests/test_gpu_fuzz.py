@@ -1,0 +1,90 @@
+"""Seeded random sweep of the PageRank path through the C ABI against the CPU oracle: small random
+graphs (uniform, star-heavy, with isolated vertices, self-loops and parallel edges) crossed with
+the options of the call -- weights and their type, id type, renumber, stored orientation, alpha,
+initial guess, personalization, precomputed out-weight sums, iteration limit -- with and without
+XS tiles / compact sources / the low-degree source ordering forced onto the small graph."""
+import numpy as np
+import pytest
+
+from helpers import make_sg_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_graph(rng, kind):
+    nv = int(rng.integers(2, 400))
+    ne = int(rng.integers(1, 12 * nv))
+    if kind == "uniform":
+        src, dst = rng.integers(0, nv, ne), rng.integers(0, nv, ne)
+    elif kind == "hubs":  # a few vertices take most edges, on either end
+        hubs = rng.integers(0, nv, 3)
+        src = np.where(rng.random(ne) < 0.5, rng.choice(hubs, ne), rng.integers(0, nv, ne))
+        dst = np.where(rng.random(ne) < 0.5, rng.choice(hubs, ne), rng.integers(0, nv, ne))
+    else:  # "sparse": most vertices untouched, some self-loops and repeated edges
+        live = rng.choice(nv, max(2, nv // 5), replace=False)
+        src, dst = rng.choice(live, ne), rng.choice(live, ne)
+        src[: ne // 10] = dst[: ne // 10]
+    return nv, src.astype(np.int64), dst.astype(np.int64)
+
+
+@pytest.mark.parametrize("engine", ["buckets", "xs", "xs_forced_layouts"])
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graphs_and_options(seed, engine, monkeypatch):
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    if engine == "buckets":
+        monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", str(1 << 40))
+    else:
+        monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0")
+    if engine == "xs_forced_layouts":
+        monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1")
+        monkeypatch.setenv("CUGRAPH_AMD_RENUMBER_LOCALITY", "1")
+        monkeypatch.setenv("CUGRAPH_AMD_XS_TILE_EDGES", "64")
+        monkeypatch.setenv("CUGRAPH_AMD_XS_PIECE", "16")
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(6):
+        nv, src, dst = _random_graph(rng, ["uniform", "hubs", "sparse"][case % 3])
+        weighted = bool(rng.integers(0, 2))
+        wdtype = np.float64 if (weighted and rng.integers(0, 2)) else np.float32
+        id_dtype = np.int64 if rng.integers(0, 2) else np.int32
+        renumber = bool(rng.integers(0, 2))
+        transposed = bool(rng.integers(0, 4))  # mostly stored the way PageRank wants it
+        alpha = float(rng.choice([0.5, 0.85, 0.95, 1.0]))
+        max_it = int(rng.choice([1, 3, 500]))
+        wgt = (rng.random(len(src)) + 0.05).astype(wdtype) if weighted else None
+        val_dtype = wdtype if weighted else np.float32
+        g, h = make_sg_graph(src.astype(id_dtype), dst.astype(id_dtype), wgt, store_transposed=transposed,
+                             renumber=renumber, vertices=np.arange(nv, dtype=id_dtype), multigraph=True)
+        kw, args = {}, [None, None, None, None]
+        if rng.integers(0, 2):  # partial initial guess
+            gv = rng.permutation(nv)[: max(1, nv // 2)]
+            gx = rng.random(len(gv)) / len(gv)
+            ns = np.zeros(nv)
+            ns[gv] = gx.astype(val_dtype)
+            kw["nstart"] = ns
+            args[2], args[3] = to_dev(gv.astype(id_dtype)), to_dev(gx.astype(val_dtype))
+        if rng.integers(0, 3) == 0:  # the caller's out-weight sums (true sums scaled: any consistent scaling goes through)
+            ow = np.bincount(src, weights=None if wgt is None else wgt.astype(np.float64), minlength=nv) * 1.5
+            kw["out_weight_sums"] = ow.astype(val_dtype).astype(np.float64)
+            args[0], args[1] = to_dev(np.arange(nv, dtype=id_dtype)), to_dev(ow.astype(val_dtype))
+        eps = 1e-7 if val_dtype == np.float32 else 1e-12
+        if rng.integers(0, 2):
+            pv = rng.permutation(nv)[: max(1, nv // 7)]
+            px = (rng.random(len(pv)) + 0.1).astype(val_dtype)
+            kw["pers_vertices"], kw["pers_values"] = pv, px
+            out = plc.personalized_pagerank(h, g, *args, to_dev(pv.astype(id_dtype)), to_dev(px), alpha, eps, max_it,
+                                            False, fail_on_nonconvergence=False)
+        else:
+            out = plc.pagerank(h, g, *args, alpha, eps, max_it, False, fail_on_nonconvergence=False)
+        c_off, c_idx, perm = oracle.compress(nv, dst, src)
+        o_pr, o_it, o_conv = oracle.pagerank(nv, c_off, c_idx, None if wgt is None else wgt[perm], dtype=np.float64,
+                                             alpha=alpha, epsilon=eps, max_iterations=max_it, **kw)
+        got = np.empty(nv)
+        got[out[0].cpu().numpy()] = out[1].cpu().numpy()
+        tol = 2e-6 if val_dtype == np.float32 else 1e-10
+        what = f"seed {seed} case {case}: nv {nv} ne {len(src)} w {weighted}/{wdtype.__name__} ids {id_dtype.__name__} " \
+               f"renumber {renumber} transposed {transposed} alpha {alpha} max_it {max_it} opts {sorted(kw)}"
+        assert np.max(np.abs(got - o_pr)) <= tol * max(1.0, float(np.abs(o_pr).max())), what
+        if max_it < 500:
+            assert bool(out[2]) == o_conv, what
