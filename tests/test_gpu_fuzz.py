@@ -88,3 +88,50 @@ def test_random_graphs_and_options(seed, engine, monkeypatch):
         assert np.max(np.abs(got - o_pr)) <= tol * max(1.0, float(np.abs(o_pr).max())), what
         if max_it < 500:
             assert bool(out[2]) == o_conv, what
+
+
+@pytest.mark.parametrize("engine", ["buckets", "xs_forced_layouts"])
+@pytest.mark.parametrize("seed", range(6))
+def test_random_graphs_katz_and_hits(seed, engine, monkeypatch):
+    """The sibling power iterations on the same random graphs: Katz (always convergent for alpha
+    under 1 / the largest weighted in-degree) with and without per-vertex betas, and HITS where
+    its iteration settles, against oracle/np_centrality.py."""
+    from oracle import np_centrality as npc
+    from cugraph_amd import pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", str(1 << 40) if engine == "buckets" else "0")
+    if engine != "buckets":
+        monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1")
+        monkeypatch.setenv("CUGRAPH_AMD_RENUMBER_LOCALITY", "1")
+        monkeypatch.setenv("CUGRAPH_AMD_XS_TILE_EDGES", "64")
+        monkeypatch.setenv("CUGRAPH_AMD_XS_PIECE", "16")
+    rng = np.random.default_rng(2000 + seed)
+    for case in range(4):
+        nv, src, dst = _random_graph(rng, ["uniform", "hubs", "sparse"][case % 3])
+        dtype = np.float64 if rng.integers(0, 2) else np.float32
+        wgt = (rng.random(len(src)) + 0.05).astype(dtype)
+        renumber = bool(rng.integers(0, 2))
+        g, h = make_sg_graph(src.astype(np.int32), dst.astype(np.int32), wgt, renumber=renumber,
+                             vertices=np.arange(nv, dtype=np.int32), multigraph=True)
+        tol = 2e-5 if dtype == np.float32 else 1e-9
+        alpha = 0.5 / np.bincount(dst, weights=wgt.astype(np.float64), minlength=nv).max()
+        betas = (rng.random(nv) + 0.5).astype(dtype) if rng.integers(0, 2) else None
+        v, x = plc.katz_centrality(h, g, None if betas is None else to_dev(betas), alpha, 1.0, 1e-9, 1000, False)
+        want, _ = npc.katz_centrality(nv, src, dst, wgt, alpha=alpha, beta=1.0, betas=betas, epsilon=1e-9,
+                                      max_iterations=1000)
+        got = np.empty(nv)
+        got[v.cpu().numpy()] = x.cpu().numpy()
+        assert np.max(np.abs(got - want)) < tol, f"katz seed {seed} case {case} nv {nv} renumber {renumber}"
+        try:
+            wh, wa, _, _ = npc.hits(nv, src, dst, epsilon=1e-7, max_iterations=300, normalize=True)
+        except RuntimeError:
+            continue  # this graph's HITS iteration does not settle: nothing to compare
+        try:
+            v, hubs, auth = plc.hits(h, g, 1e-7, 300, None, None, True, False)
+        except RuntimeError:
+            # the device run carries fp32 / atomics-order noise: a run that converges on the limit may differ
+            continue
+        gh, ga = np.empty(nv), np.empty(nv)
+        gh[v.cpu().numpy()], ga[v.cpu().numpy()] = hubs.cpu().numpy(), auth.cpu().numpy()
+        assert np.max(np.abs(gh - wh)) < 50 * tol and np.max(np.abs(ga - wa)) < 50 * tol, \
+            f"hits seed {seed} case {case} nv {nv} renumber {renumber}"
