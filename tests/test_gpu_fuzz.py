@@ -135,3 +135,74 @@ def test_random_graphs_katz_and_hits(seed, engine, monkeypatch):
         gh[v.cpu().numpy()], ga[v.cpu().numpy()] = hubs.cpu().numpy(), auth.cpu().numpy()
         assert np.max(np.abs(gh - wh)) < 50 * tol and np.max(np.abs(ga - wa)) < 50 * tol, \
             f"hits seed {seed} case {case} nv {nv} renumber {renumber}"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graph_builds(seed):
+    """The build alone on random edge lists and options: COO or CSR input, either orientation,
+    int32 / int64 ids, renumbering (plain ids or ids with gaps and negatives), weights of either
+    type, drop_self_loops / drop_multi_edges, do_expensive_check.  The stored graph is the
+    oracle's (major, minor)-sorted compression of the expected edge list, weights in input order
+    among equal edges; with renumbering: in descending major degree through the number map."""
+    import torch
+    import oracle
+    from helpers import compressed_arrays
+    from cugraph_amd import pylibcugraph as plc
+
+    rng = np.random.default_rng(3000 + seed)
+    dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for case in range(8):
+        nv, src, dst = _random_graph(rng, ["uniform", "hubs", "sparse"][case % 3])
+        id_dtype = np.int64 if rng.integers(0, 2) else np.int32
+        transposed, renumber = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        weighted = bool(rng.integers(0, 2))
+        wdtype = np.float64 if rng.integers(0, 2) else np.float32
+        wgt = (rng.random(len(src)) + 0.05).astype(wdtype) if weighted else None
+        drop_loops, drop_multi = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        csr = bool(rng.integers(0, 3) == 0) and not renumber
+        ext = np.arange(nv, dtype=np.int64)
+        if renumber and rng.integers(0, 2):
+            ext = ext * 5 - 17  # gaps and negative ids
+        what = f"seed {seed} case {case}: nv {nv} ne {len(src)} ids {id_dtype.__name__} transposed {transposed} " \
+               f"renumber {renumber} weighted {weighted} drop {drop_loops}/{drop_multi} csr {csr}"
+        h = plc.ResourceHandle()
+        props = plc.GraphProperties(is_symmetric=False, is_multigraph=not drop_multi)
+        if csr:  # CSR input: offsets over sources; the edge list it stands for is (src, dst) sorted by src
+            o = np.argsort(src, kind="stable")
+            src, dst, wgt = src[o], dst[o], (None if wgt is None else wgt[o])
+            offs = np.zeros(nv + 1, np.int64)
+            np.cumsum(np.bincount(src, minlength=nv), out=offs[1:])
+            g = plc.SGGraph(h, plc.GraphProperties(is_symmetric=False, is_multigraph=True), dev(offs.astype(id_dtype)),
+                            dev(dst.astype(id_dtype)), weight_array=dev(wgt), store_transposed=transposed,
+                            renumber=False, do_expensive_check=True, input_array_format="CSR")
+            drop_loops_eff = drop_multi_eff = False
+        else:
+            g = plc.SGGraph(h, props, dev(ext[src].astype(id_dtype)), dev(ext[dst].astype(id_dtype)),
+                            weight_array=dev(wgt), store_transposed=transposed, renumber=renumber,
+                            do_expensive_check=True, vertices_array=dev(ext.astype(id_dtype)),
+                            drop_self_loops=drop_loops, drop_multi_edges=drop_multi)
+            drop_loops_eff, drop_multi_eff = drop_loops, drop_multi
+        s, d, x = src, dst, wgt
+        if drop_loops_eff:
+            keep = s != d
+            s, d, x = s[keep], d[keep], (None if x is None else x[keep])
+        if drop_multi_eff:  # the first copy in input order survives (not flagged symmetric)
+            _, first_pos = np.unique(np.stack([s, d], 1), axis=0, return_index=True)
+            first_pos.sort()
+            s, d, x = s[first_pos], d[first_pos], (None if x is None else x[first_pos])
+        off, idx, w, nmap = compressed_arrays(g, h)
+        assert g.info()["num_vertices"] == nv and int(off[-1]) == len(s), what
+        if renumber:
+            assert nmap is not None and nmap.dtype == id_dtype and sorted(nmap.tolist()) == sorted(ext.tolist()), what
+            inv = {int(e): i for i, e in enumerate(nmap)}
+            s2 = np.array([inv[int(e)] for e in ext[s]], np.int64)
+            d2 = np.array([inv[int(e)] for e in ext[d]], np.int64)
+            deg = np.diff(off)
+            assert np.all(deg[:-1] >= deg[1:]), what
+        else:
+            s2, d2 = s, d
+        major, minor = (d2, s2) if transposed else (s2, d2)
+        o_off, o_idx, o_w = oracle.csc_lexsort(nv, minor, major, x)
+        assert np.array_equal(off.astype(np.int64), o_off) and np.array_equal(idx, o_idx), what
+        if weighted:
+            assert w.dtype == wdtype and np.array_equal(w, o_w), what
