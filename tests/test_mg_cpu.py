@@ -175,3 +175,26 @@ def test_mg_c_api_goldens(name, world, tmp_path):
     for f, m in zip(fulls, metas):
         assert np.all(np.abs(f - want) <= 1e-3 * np.maximum(np.abs(f), np.abs(want)))
         assert bool(m[3]) == (not c["allow_nonconvergence"])
+
+
+@pytest.mark.parametrize("seed,world", [(0, 2), (1, 3), (2, 4), (3, 5)])
+def test_mg_random_small_graphs(seed, world, tmp_path):
+    """Small random graphs through the driver -- isolated vertices, self-loops, parallel edges,
+    ranks that own few or no vertices or receive no edges -- with regions and the source ordering
+    of the low-degree rows forced on, sharded personalization and initial guess."""
+    rng = np.random.default_rng(500 + seed)
+    nv = int(rng.integers(world - 1, 60))  # may leave the last rank(s) without vertices
+    ne = int(rng.integers(1, 6 * nv + 2))
+    live = rng.choice(nv, max(1, nv // 2), replace=False)
+    src, dst = rng.choice(live, ne).astype(np.int64), rng.choice(live, ne).astype(np.int64)
+    wgt = rng.random(ne) + 0.05 if seed % 2 else None
+    pers = (rng.permutation(nv)[: max(1, nv // 5)].astype(np.int64), rng.random(max(1, nv // 5)) + 0.1)
+    nstart = (rng.permutation(nv)[: max(1, nv // 2)].astype(np.int64), rng.random(max(1, nv // 2)) / nv)
+    case = dict(src=src, dst=dst, wgt=wgt, nv=nv, eps=1e-12, max_iter=60, check=2, regions="1", locality="1",
+                pers=pers, nstart=nstart, sharded=True)
+    fulls, metas = _run(world, case, tmp_path)
+    o_pr, o_it, o_conv = _oracle(case)
+    for f, m in zip(fulls, metas):
+        assert bool(m[3]) == o_conv and (m[0] == o_it or wgt is None)
+        # (an unweighted graph's values are fp32 at the API: the lists are rounded on their way in)
+        assert np.max(np.abs(f - o_pr)) < (1e-12 if wgt is not None else 1e-7)
