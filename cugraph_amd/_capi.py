@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcugraph_amd_c.so")
+# CUGRAPH_AMD_LIBRARY: another build of the same library (e.g. the timing-aid build, `make AIDS=1`)
+LIB_PATH = os.environ.get("CUGRAPH_AMD_LIBRARY") or os.path.join(_HERE, "libcugraph_amd_c.so")
 
 # cugraph_data_type_id_t (reference: cpp/include/cugraph_c/resource_handle.h:35)
 INT32, INT64, FLOAT32, FLOAT64, SIZE_T = 0, 1, 2, 3, 4

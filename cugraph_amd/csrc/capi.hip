@@ -1040,7 +1040,7 @@ cugraph_error_code_t cugraph_amd_pagerank_session_exchange_buffers(
     session_exchange_buffers(s, &x, &sc);
     *x_full  = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
       new_view(x, static_cast<size_t>(session_num_global(s)), session_is_f64(s) ? FLOAT64 : FLOAT32));
-    *scalars = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(sc, 2, FLOAT64));
+    *scalars = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new_view(sc, 4, FLOAT64));
   });
 }
 

@@ -54,6 +54,7 @@ constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longe
 constexpr int kXsRowBits      = 12;
 constexpr int kXsRowBitsMax   = 14;
 constexpr int kXsMinDegree    = kLowDegreeMax + 1;
+constexpr int64_t kXsLongRow = 4096;  // rows with more edges than this keep fp64 accumulators (xs_acc_bytes mode 2)
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
 // a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile
@@ -93,12 +94,23 @@ struct XsArgs {
   int* counters;             // [8] next item of each slice's queue
   int64_t row_first, n_rows;
   int n_tiles;
-  int affinity_mode;  // 0: queue of the XCD we run on; 1, 2: timing aids (blockIdx based)
-  int search_windows; // window of an entry by binary search of the record (more than 16 windows; or forced, for tests)
+#ifdef CGA_TIMING_AIDS
+  int affinity_mode;     // 0: queue of the XCD we run on; 1, 2: blockIdx based
+  int profile;           // per-workgroup times into xs_prof_buf
+  uint32_t gather_mask;  // narrows every gathered index (results are then wrong)
+  int no_atomics;        // row sums are not accumulated (one add per lane and pass keeps the loads alive)
+#endif
 };
 
+// Timing aids (CUGRAPH_AMD_GATHER_MASK, _BUCKET_MASK, _XS_AFFINITY, _XS_PROFILE) exist only in a
+// library built with `make AIDS=1`; the shipped kernels carry none of them.
+#ifdef CGA_TIMING_AIDS
+#define CGA_GMASK(args, i) ((i) & (args).gather_mask)
+#else
+#define CGA_GMASK(args, i) (i)
+#endif
+
 constexpr int kXsRecWords   = 64;  // one load of the first wave
-constexpr int kXsRegWindows = 16;  // window starts kept in scalar registers (graphs with up to 16 windows)
 constexpr int kXsRecWindows = kXsRecWords - 4;  // window starts a record carries: wide tiles up to this many
 
 // one piece of a hub column; its partial sum lands in item_partial[item]
@@ -141,7 +153,9 @@ struct IterArgs {
   ValT num_vertices;  // global vertex count as a value
   double epsilon;
   int personalized;
-  uint32_t gather_mask;  // 0xFFFFFFFF; a timing aid can narrow it (CUGRAPH_AMD_GATHER_MASK)
+#ifdef CGA_TIMING_AIDS
+  uint32_t gather_mask;
+#endif
   int64_t vertex_first;
   ValT* raw_out;         // not nullptr: plain SpMV, row sums go here and nothing else happens
   int32_t const* x_pos;  // slot of row v in the gathered vector, -1: nobody gathers it; nullptr: vertex_first + v
@@ -299,7 +313,7 @@ __device__ inline double column_partial(IterArgs<OffT, ValT> const& a, OffT beg,
                       (uint32_t)r.x, (uint32_t)r.y, (uint32_t)r.z, (uint32_t)r.w};
     ValT xv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xv[k] = p[k] ? a.x_cur[gi[k] & a.gather_mask] : ValT(0);
+    for (int k = 0; k < 8; ++k) xv[k] = p[k] ? a.x_cur[CGA_GMASK(a, gi[k])] : ValT(0);
     if constexpr (WEIGHTED) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) xv[k] *= w[k];
@@ -372,7 +386,7 @@ __device__ inline void thread_bucket(IterArgs<OffT, ValT> const& a, Bucket const
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int d = 0; d < D; ++d) xv[r][d] = a.x_cur[idx[r][d] & a.gather_mask];
+      for (int d = 0; d < D; ++d) xv[r][d] = a.x_cur[CGA_GMASK(a, idx[r][d])];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       ValT acc = 0;
@@ -508,33 +522,64 @@ __device__ inline void stream_load4(uint32_t const* p, uint32_t* r)
 // (slice, row); xs_finish_kernel adds the 8 partials and runs the epilogue.  Workgroups pull
 // tiles from the queue of the XCD they run on (HW_REG_XCC_ID) and steal from the other queues
 // when theirs is empty, so the result never depends on where a workgroup was placed.
-// timing aid (CUGRAPH_AMD_XS_PROFILE=1): per-workgroup time in set-up / passes / write-back
-__device__ unsigned long long xs_prof_buf[1024 * 8];
+// what xs_kernel needs of an iteration (the tiles carry their own layout: no offsets type)
+template <typename ValT>
+struct XsLaunch {
+  XsArgs<ValT> xs;
+  ValT const* x_cur;
+  double const* scal;
+  Ctrl* ctrl;
+  double epsilon;
+};
 
-template <typename OffT, typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, bool PROFILE = false>
-__global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
+// accumulators of a tile, per workgroup.  ACCMODE 0: fp64, 2^ROWBITS of them.  1: fp32.  2: the
+// same bytes hold 2^ROWBITS fp32 accumulators for a tile with more than 2^(ROWBITS-1) rows -- the
+// low-degree tiles, whose row sums have few terms -- and 2^(ROWBITS-1) fp64 ones for every other
+// tile (the long rows: the first tiles of a degree-sorted graph stop at kXsTileEdges edges, not at
+// the row limit).
+__host__ __device__ constexpr int xs_acc_bytes(int row_bits, int acc_mode)
 {
-  using XsAcc = double;
+  return acc_mode == 0 ? (8 << row_bits) : (4 << row_bits);
+}
+
+#ifdef CGA_TIMING_AIDS
+// per-workgroup time in set-up / passes / write-back (make AIDS=1; CUGRAPH_AMD_XS_PROFILE=1)
+__device__ unsigned long long xs_prof_buf[1024 * 8];
+#define CGA_XSP(stmt) do { if (a.xs.profile) { stmt; } } while (0)
+#else
+#define CGA_XSP(stmt) do { } while (0)
+#endif
+
+// WPE: waves per SIMD the register allocation must allow (THREADS / 256 = one workgroup per CU)
+template <typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EPL, int ACCMODE, int WPE = THREADS / 256>
+__global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
+{
+  static_assert(ACCMODE == 0 || std::is_same<ValT, float>::value, "fp32 accumulators: fp32 graphs only");
   constexpr int kLowBits       = 32 - ROWBITS;
   constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
-  constexpr int EPL            = kXsEntriesPerLane;
   constexpr uint32_t kPass     = THREADS * EPL;  // entries per pass of the workgroup
+  constexpr int kAccBytes      = xs_acc_bytes(ROWBITS, ACCMODE);
   extern __shared__ double xs_lds[];
-  XsAcc* acc = xs_lds;  // [2^ROWBITS]
+  double* const acc64 = xs_lds;
+  float* const acc32  = reinterpret_cast<float*>(xs_lds);
   __shared__ int64_t s_rec[2][kXsRecWords];
   if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
   XsArgs<ValT> const& xs = a.xs;
   int const tid  = threadIdx.x;
   int const lane = tid & 63;
   bool const wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+#ifdef CGA_TIMING_AIDS
   int const my  = xs.affinity_mode == 0   ? static_cast<int>(xcc_id() & (kXsSlices - 1))
                   : xs.affinity_mode == 1 ? static_cast<int>(blockIdx.x & (kXsSlices - 1))
                                           : static_cast<int>((blockIdx.x >> 3) & (kXsSlices - 1));
   unsigned long long pt_setup = 0, pt_pass = 0, pt_wb = 0, pt_n = 0, pt_stolen = 0, pt_a = 0, pt_b = 0;
-  unsigned long long const pt_t0 = PROFILE ? wall_clock64() : 0ull;
-  // the accumulators start at zero and every write-back leaves them at zero
-  for (int i = tid; i < (1 << ROWBITS); i += THREADS) acc[i] = 0;
-  // record of queue item q of slice k (lanes 0..15 of the first wave, 8 bytes each); -1: queue empty
+  unsigned long long const pt_t0 = wall_clock64();
+#else
+  int const my = static_cast<int>(xcc_id() & (kXsSlices - 1));
+#endif
+  // the accumulators start at zero (all-zero bytes: either type) and every write-back leaves them so
+  for (int i = tid; i < kAccBytes / 4; i += THREADS) acc32[i] = 0.f;
+  // record of queue item q of slice k (the first wave, 8 bytes a lane); -1: queue empty
   auto load_record = [&](int k, int q) -> int64_t {
     int64_t r = -1;
     if (lane < kXsRecWords && q < xs.n_items)
@@ -544,7 +589,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
   int buf = 0;
   for (int rot = 0; rot < kXsSlices; ++rot) {
     int const k = (my + rot) & (kXsSlices - 1);
-    if constexpr (PROFILE) pt_a = wall_clock64();
+    CGA_XSP(pt_a = wall_clock64());
     // the first item of a queue is fetched on the spot, every later one during the item before it
     if (wave0) {
       int q = 0;
@@ -570,53 +615,46 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
       // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
       // so every lane keeps the 4 row sums in registers and the block reduces them at the end
       bool const few = rows <= 4;
+      bool const use32 = ACCMODE == 1 || (ACCMODE == 2 && rows > (1 << (ROWBITS - 1)));
       double racc[4] = {0.0, 0.0, 0.0, 0.0};
       int const shift = xs.slice_shift;
       // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
-      // from its position (boundaries relative to the aligned start; up to 16 kept in registers)
+      // from its position.  bound(w): first position of window w relative to the aligned start
+      // (0 for a window that starts before this item's entries -- an item can be the tail of a
+      // unit: the second region of a partitioned graph --, 2^32 - 1 for windows past the last).
       int64_t const u0    = ((int64_t)t * kXsSlices + k) * xs.n_win;
       int64_t const beg   = uniform64(rec[3]);
       int64_t const end   = uniform64(rec[4]);
       int64_t const abeg  = beg & ~int64_t(3);
       uint32_t const rbeg = static_cast<uint32_t>(beg - abeg);
       uint32_t const rend = static_cast<uint32_t>(end - abeg);
-      uint32_t wb[kXsRegWindows];
-#pragma unroll
-      for (int w = 1; w < kXsRegWindows; ++w) {
-        // INT64_MAX for windows the graph does not have; a window that starts before this item's
-        // entries (an item can be the tail of a unit: the second region of a partitioned graph)
-        int64_t d = uniform64(rec[4 + w]) - abeg;
-        wb[w]     = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : d < 0 ? 0u : static_cast<uint32_t>(d);
-      }
       int const n_win = xs.n_win;
-      auto window_of = [&](uint32_t pos) {
-        uint32_t c = 0;
-        if (!xs.search_windows) {
-#pragma unroll
-          for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
-        } else if (n_win <= kXsRecWindows) {
-          // many windows (a huge source space under wide tiles): binary search of the record in
-          // LDS for the last window that starts at or before the entry
-          int64_t const p = abeg + static_cast<int64_t>(pos);
-          uint32_t lo = 0, hi = static_cast<uint32_t>(n_win) - 1u;  // answer in [lo, hi]
-          while (lo < hi) {
-            uint32_t mid = (lo + hi + 1u) >> 1;
-            if (rec[4 + mid] <= p) lo = mid; else hi = mid - 1u;
-          }
-          c = lo;
-        } else {  // beyond what a record carries (narrow tiles over more than 2^29 slots)
-#pragma unroll
-          for (int w = 1; w < kXsRegWindows; ++w) c += pos >= wb[w] ? 1u : 0u;
-          for (int w = kXsRegWindows; w < n_win; ++w)
-            c += static_cast<int64_t>(pos) >= xs.unit_off[u0 + w] - abeg ? 1u : 0u;
-        }
-        return c;
+      auto bound = [&](int w) -> uint32_t {
+        if (w <= 0) return 0u;
+        if (w >= n_win) return 0xFFFFFFFFu;
+        // a record carries the starts of windows 1 .. kXsRecWindows - 1; beyond: from memory
+        int64_t const s = w < kXsRecWindows ? uniform64(rec[4 + w]) : xs.unit_off[u0 + w];
+        int64_t const d = s - abeg;
+        return d > 0xFFFFFFFELL ? 0xFFFFFFFFu : d < 0 ? 0u : static_cast<uint32_t>(d);
       };
       uint32_t const low_mask = (1u << shift) - 1u;
       // this piece's share of the unit's passes
       uint32_t const n_pass = (rend + kPass - 1) / kPass;
       uint32_t const pb_lo  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * piece / n_pc) * kPass;
       uint32_t const pb_hi  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * (piece + 1) / n_pc) * kPass;
+      // window of the piece's first entry: the last one that starts at or before it (the starts
+      // ascend; empty windows share a start with their successor)
+      int w_cur = 0;
+      {
+        uint32_t const p0 = pb_lo > rbeg ? pb_lo : rbeg;
+        int lo = 0, hi = n_win - 1;
+        while (lo < hi) {
+          int const mid = (lo + hi + 1) >> 1;
+          if (bound(mid) <= p0) lo = mid; else hi = mid - 1;
+        }
+        w_cur = lo;
+      }
+      uint32_t nb = bound(w_cur + 1);  // where the next window starts
       // One pass of the workgroup covers THREADS * EPL entries, EPL per lane; entry e of lane tid is
       // pb + e * THREADS + tid, so that the 64 lanes of one gather instruction hold 64 CONSECUTIVE
       // entries (ascending sources: few cache lines per instruction).  The loop is software
@@ -637,23 +675,32 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
           if constexpr (WEIGHTED) w_out[e] = __builtin_nontemporal_load(xs.w + abeg + q);
         }
       };
-      auto pass = [&](auto fast_tag, uint32_t pb, uint32_t win_uniform) {
+      auto pass = [&](auto fast_tag, auto a32_tag, uint32_t pb, int w_lo, int w_hi) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr bool A32  = decltype(a32_tag)::value;
         uint32_t const pos = pb + static_cast<uint32_t>(tid);
         bool p[EPL];
-        uint32_t loc[EPL];  // slice-local source position
+        uint32_t wn[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          uint32_t q  = pos + e * THREADS;
-          p[e]        = FAST || (q >= rbeg && q < rend);
-          uint32_t wn = FAST ? win_uniform : window_of(q);
-          loc[e]      = (wn << kLowBits) | (en[e] >> ROWBITS);
+          uint32_t q = pos + e * THREADS;
+          p[e]       = FAST || (q >= rbeg && q < rend);
+          wn[e]      = static_cast<uint32_t>(w_lo);
+        }
+        if constexpr (!FAST) {
+          // the pass crosses window starts: count the ones at or before each entry
+          for (int wi = w_lo + 1; wi <= w_hi; ++wi) {
+            uint32_t const b = bound(wi);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) wn[e] += pos + e * THREADS >= b ? 1u : 0u;
+          }
         }
         ValT xv[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          uint32_t gi = ((loc[e] & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc[e] & low_mask);
-          xv[e]       = p[e] ? a.x_cur[gi & a.gather_mask] : ValT(0);
+          uint32_t const loc = (wn[e] << kLowBits) | (en[e] >> ROWBITS);  // slice-local source position
+          uint32_t gi = ((loc & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc & low_mask);
+          xv[e]       = p[e] ? a.x_cur[CGA_GMASK(a.xs, gi)] : ValT(0);
         }
         uint32_t en_next[EPL];
         ValT w_next[EPL];
@@ -670,10 +717,22 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) racc[rr] += rl == (uint32_t)rr ? v : 0.0;
           }
+#ifdef CGA_TIMING_AIDS
+        } else if (xs.no_atomics) {
+          ValT sum = 0;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
+          if (sum == ValT(-1)) atomicAdd(&acc64[0], 1.0);
+#endif
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e)
-            if (p[e]) atomicAdd(&acc[en[e] & kRowMask], static_cast<XsAcc>(xv[e]));
+            if (p[e]) {
+              if constexpr (A32)
+                atomicAdd(&acc32[en[e] & kRowMask], static_cast<float>(xv[e]));
+              else
+                atomicAdd(&acc64[en[e] & kRowMask], static_cast<double>(xv[e]));
+            }
         }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -681,7 +740,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
           if constexpr (WEIGHTED) w[e] = w_next[e];
         }
       };
-      if constexpr (PROFILE) { pt_b = wall_clock64(); pt_setup += pt_b - pt_a; pt_n++; pt_stolen += rot != 0; }
+      CGA_XSP(pt_b = wall_clock64(); pt_setup += pt_b - pt_a; pt_n++; pt_stolen += rot != 0);
       fetch(pb_lo, en, w);
       int64_t r_next = -1;
       int stage      = 0;  // 1: next item asked for, 2: its record requested
@@ -695,49 +754,120 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(IterArgs<OffT, ValT> a)
         }
       };
       for (uint32_t pb = pb_lo; pb < pb_hi; pb += kPass) {
-        uint32_t const w_lo = window_of(pb), w_hi = window_of(pb + kPass - 1);
-        if (pb >= rbeg && pb + kPass <= rend && w_lo == w_hi)
-          pass(std::true_type{}, pb, w_lo);
-        else
-          pass(std::false_type{}, pb, 0u);
+        uint32_t const pe = pb + kPass;
+        if (pb >= rbeg && pe <= rend && pe <= nb) {
+          if constexpr (ACCMODE == 2) {
+            if (use32) pass(std::true_type{}, std::true_type{}, pb, w_cur, w_cur);
+            else pass(std::true_type{}, std::false_type{}, pb, w_cur, w_cur);
+          } else {
+            pass(std::true_type{}, std::integral_constant<bool, ACCMODE == 1>{}, pb, w_cur, w_cur);
+          }
+        } else {
+          int w_hi = w_cur;
+          while (nb < pe && w_hi + 1 < n_win) {  // window w_hi + 1 starts inside this pass
+            ++w_hi;
+            nb = bound(w_hi + 1);
+          }
+          if constexpr (ACCMODE == 2) {
+            if (use32) pass(std::false_type{}, std::true_type{}, pb, w_cur, w_hi);
+            else pass(std::false_type{}, std::false_type{}, pb, w_cur, w_hi);
+          } else {
+            pass(std::false_type{}, std::integral_constant<bool, ACCMODE == 1>{}, pb, w_cur, w_hi);
+          }
+          w_cur = w_hi;
+        }
         if (pb + 3 * kPass >= pb_hi) look_ahead();
       }
       look_ahead();
       look_ahead();
-      if constexpr (PROFILE) { pt_a = wall_clock64(); pt_pass += pt_a - pt_b; }
+      CGA_XSP(pt_a = wall_clock64(); pt_pass += pt_a - pt_b);
       if (few) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           double v = group_sum(racc[rr], 64);
-          if (lane == 0 && rr < rows) atomicAdd(&acc[rr], v);
+          if (lane == 0 && rr < rows) {
+            if (use32) atomicAdd(&acc32[rr], static_cast<float>(v));
+            else atomicAdd(&acc64[rr], v);
+          }
         }
       }
       __syncthreads();
-      for (int i = tid; i < rows; i += THREADS) {
-        __builtin_nontemporal_store(static_cast<ValT>(acc[i]), out + i);
-        acc[i] = 0;
+      if (use32) {
+        for (int i = tid; i < rows; i += THREADS) {
+          __builtin_nontemporal_store(static_cast<ValT>(acc32[i]), out + i);
+          acc32[i] = 0.f;
+        }
+      } else {
+        for (int i = tid; i < rows; i += THREADS) {
+          __builtin_nontemporal_store(static_cast<ValT>(acc64[i]), out + i);
+          acc64[i] = 0.0;
+        }
       }
       if (wave0 && lane < kXsRecWords) s_rec[buf ^ 1][lane] = r_next;
       buf ^= 1;
       __syncthreads();
-      if constexpr (PROFILE) pt_wb += wall_clock64() - pt_a;
+      CGA_XSP(pt_wb += wall_clock64() - pt_a);
     }
   }
-  if constexpr (PROFILE) {
-    if (tid == 0 && blockIdx.x < 1024) {
-      unsigned long long* o = xs_prof_buf + 8 * blockIdx.x;
-      o[0] = my; o[1] = wall_clock64() - pt_t0; o[2] = pt_setup; o[3] = pt_pass; o[4] = pt_wb; o[5] = pt_n; o[6] = pt_stolen;
-      o[7] = pt_t0;
-    }
+#ifdef CGA_TIMING_AIDS
+  if (xs.profile && tid == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = xs_prof_buf + 8 * blockIdx.x;
+    o[0] = my; o[1] = wall_clock64() - pt_t0; o[2] = pt_setup; o[3] = pt_pass; o[4] = pt_wb; o[5] = pt_n; o[6] = pt_stolen;
+    o[7] = pt_t0;
   }
+#endif
 }
 
+#ifdef CGA_TIMING_AIDS
 __global__ void xs_prof_dump_kernel(int n)
 {
   for (int i = 0; i < n; ++i) {
     unsigned long long* o = xs_prof_buf + 8 * i;
     printf("XSP %d %llu %llu %llu %llu %llu %llu %llu %llu\n", i, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
   }
+}
+#endif
+
+// the instantiations of xs_kernel that exist, by what the plan says of its tiles
+template <typename ValT>
+struct XsKernelChoice {
+  void (*kern)(XsLaunch<ValT>);
+  int threads;
+  int lds;
+};
+
+constexpr int xs_threads_for(int row_bits)
+{
+  return row_bits >= 14 ? 1024 : kThreads << (row_bits - kXsRowBits);
+}
+
+template <typename ValT>
+XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl, int acc_mode, int wpe = 0)
+{
+#define CGA_XS_CASE_W(W, RB, EPL, ACC, WPE)                                                    \
+  if (weighted == W && row_bits == RB && epl == EPL && acc_mode == ACC && (wpe == WPE || (wpe == 0 && WPE == xs_threads_for(RB) / 256))) \
+    return XsKernelChoice<ValT>{xs_kernel<ValT, W, xs_threads_for(RB), RB, EPL, ACC, WPE>,     \
+                                xs_threads_for(RB), xs_acc_bytes(RB, ACC)};
+#define CGA_XS_CASE(W, RB, EPL, ACC) CGA_XS_CASE_W(W, RB, EPL, ACC, xs_threads_for(RB) / 256)
+  CGA_XS_CASE(false, 12, 8, 0)
+  CGA_XS_CASE(false, 13, 8, 0)
+  CGA_XS_CASE(false, 14, 8, 0)
+  CGA_XS_CASE(true, 12, 8, 0)
+  CGA_XS_CASE(true, 13, 8, 0)
+  CGA_XS_CASE(true, 14, 8, 0)
+  if constexpr (std::is_same<ValT, float>::value) {
+    CGA_XS_CASE(false, 14, 16, 0)
+    CGA_XS_CASE(false, 14, 8, 1)
+    CGA_XS_CASE(false, 14, 16, 1)
+    CGA_XS_CASE(false, 15, 8, 1)
+    CGA_XS_CASE(false, 15, 16, 1)
+    CGA_XS_CASE(false, 15, 8, 2)
+    CGA_XS_CASE(false, 15, 16, 2)
+    CGA_XS_CASE_W(false, 14, 8, 1, 8)  // two 64 KiB workgroups per CU
+  }
+#undef CGA_XS_CASE
+#undef CGA_XS_CASE_W
+  throw Failure(CUGRAPH_UNKNOWN_ERROR, "internal: no xs_kernel for this tile layout");
 }
 
 template <typename OffT, typename ValT, bool WEIGHTED>
@@ -895,13 +1025,18 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
 template <typename OffT>
 __global__ void xs_break_flags_kernel(OffT const* __restrict__ offsets, int64_t row_first,
                                       int64_t n_rows, int64_t e0, int64_t tile_edges, int64_t max_rows,
-                                      unsigned int* __restrict__ flags)
+                                      int64_t long_row, unsigned int* __restrict__ flags)
 {
+  // long_row > 0 (tiles whose second half of rows only has fp32 accumulators, xs_acc_bytes mode 2):
+  // while the rows are longer than that, tiles stop at half the row limit and so keep fp64 sums
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t w  = (static_cast<int64_t>(offsets[row_first + i]) - e0) / tile_edges;
+    int64_t o  = static_cast<int64_t>(offsets[row_first + i]);
+    int64_t w  = (o - e0) / tile_edges;
     int64_t wp = i == 0 ? -1 : (static_cast<int64_t>(offsets[row_first + i - 1]) - e0) / tile_edges;
-    flags[i]   = (w != wp || (i % max_rows) == 0) ? 1u : 0u;
+    int64_t m  = (long_row > 0 && static_cast<int64_t>(offsets[row_first + i + 1]) - o > long_row) ? max_rows / 2
+                                                                                                    : max_rows;
+    flags[i]   = (w != wp || (i % m) == 0) ? 1u : 0u;
   }
 }
 
@@ -1086,13 +1221,17 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(double const* __rest
       ds += lds[2 * w];
       ls += lds[2 * w + 1];
     }
-    scal[0] = ds + dead_dangling;
+    // scal[0..1]: what the next iteration's kernels read; scal[2..3]: the same sums as THIS rank
+    // produced them.  A multi-GPU driver all-reduces [2..3] into [0..1] (cugraph_amd.mg): an
+    // iteration skipped after the stop leaves [2..3] alone, so reducing them again changes nothing.
+    double const d_out = ds + dead_dangling;
+    double const l_out = count_iteration ? ls + dead_delta
+                                         : 1e300;  // "no previous iteration": never below epsilon, survives an 8-rank sum
+    scal[0] = scal[2] = d_out;
+    scal[1] = scal[3] = l_out;
     if (count_iteration) {
-      scal[1] = ls + dead_delta;
       ctrl->iters += 1;
       if (dead.track) ctrl->base_prev = base;
-    } else {
-      scal[1] = 1e300;  // "no previous iteration": never below epsilon, survives an 8-rank sum
     }
   }
 }
@@ -1337,6 +1476,9 @@ struct PullPlan {
   int xs_n_items[2]{0, 0};  // work items per slice queue, per region
   int64_t xs_partial_len{0};
   int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
+  int xs_epl{kXsEntriesPerLane};  // entries a lane of xs_kernel keeps in flight per pass
+  int xs_acc_mode{0};             // accumulators of a tile: see xs_acc_bytes
+  int xs_wpe{0};                  // waves per SIMD xs_kernel's registers must allow (0: one workgroup per CU)
   DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec[2], xs_pbase, xs_fin_items;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
@@ -1417,11 +1559,11 @@ void build_plan_lists(hipStream_t stream, Graph const& g, PullPlan& plan)
 }
 
 // rows per tile (as a power of two) for a source space of `minor_space` ids or slots: see build_xs
-int xs_row_bits_for(int64_t minor_space, int slice_shift)
+int xs_row_bits_for(int64_t minor_space, int slice_shift, int max_bits = kXsRowBitsMax)
 {
   uint32_t const last_local = xs_slice_local(static_cast<uint32_t>(minor_space - 1), slice_shift) |
                               ((1u << slice_shift) - 1u);
-  int row_bits = kXsRowBitsMax;
+  int row_bits = max_bits;
   while (row_bits > kXsRowBits && (last_local >> (32 - row_bits)) >= static_cast<uint32_t>(kXsRecWindows)) --row_bits;
   return row_bits;
 }
@@ -1463,12 +1605,26 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // windows at 14 bits) 12.99 / 11.82 / 10.86.
   char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
   int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
-  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
+  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax + 1) row_bits = std::atoi(rb_env);
+  // accumulator type and entries per lane of the kernel these tiles are for (xs_pick lists what exists)
+  char const* acc_env = std::getenv("CUGRAPH_AMD_XS_ACC");
+  char const* epl_env = std::getenv("CUGRAPH_AMD_XS_EPL");
+  int acc_mode = acc_env ? std::atoi(acc_env) : 0;
+  int epl      = epl_env ? std::atoi(epl_env) : kXsEntriesPerLane;
+  if (!std::is_same<ValT, float>::value || g.weights) {
+    acc_mode = 0;
+    epl      = kXsEntriesPerLane;
+  }
+  if (acc_mode == 0 && row_bits > kXsRowBitsMax) row_bits = kXsRowBitsMax;
+  if (acc_mode == 2 && row_bits <= kXsRowBitsMax) acc_mode = 0;
+  char const* wpe_env = std::getenv("CUGRAPH_AMD_XS_WPE");
+  int const wpe = (wpe_env && acc_mode != 0 && epl == kXsEntriesPerLane) ? std::atoi(wpe_env) : 0;
+  (void)xs_pick<ValT>(g.weights != nullptr, row_bits, epl, acc_mode, wpe);  // throws if there is no such kernel
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
                      offsets, row_first, n_rows, e0, tile_edges, int64_t(1) << row_bits,
-                     flags.as<unsigned int>());
+                     acc_mode == 2 ? kXsLongRow : int64_t(0), flags.as<unsigned int>());
   exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n_rows, pos.as<int64_t>());
   int64_t n_tiles64 = 0;
   CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
@@ -1535,7 +1691,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   char const* pc_env     = std::getenv("CUGRAPH_AMD_XS_PIECE");
   // a piece is 64 passes of its workgroup (128 of a 256-thread one); small graphs: down to 16, so
   // that there are a few thousand pieces
-  int64_t const pass_entries = int64_t(kThreads * kXsEntriesPerLane) << (row_bits - kXsRowBits);
+  int64_t const pass_entries = int64_t(xs_threads_for(row_bits)) * epl;
   int64_t piece_entries      = row_bits == kXsRowBits ? kXsPieceEntries : 64 * pass_entries;
   while (piece_entries > 16 * pass_entries && piece_entries * 1024 > ne) piece_entries >>= 1;
   if (pc_env) piece_entries = std::atoll(pc_env);
@@ -1619,6 +1775,9 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_n_win     = n_win;
   plan.xs_slice_shift = slice_shift;
   plan.xs_row_bits  = row_bits;
+  plan.xs_epl       = epl;
+  plan.xs_acc_mode  = acc_mode;
+  plan.xs_wpe       = wpe;
 }
 
 template <typename OffT>
@@ -1877,6 +2036,8 @@ struct Session {
   bool xs_on{false};
   int64_t n_dead{0};  // trailing rows no edge touches, skipped after the first iteration
   int xs_block_begin{0}, n_xs_blocks{0}, n_xs_finish_blocks{0};
+  void* xs_kernel_fn{nullptr};  // the xs_kernel instantiation of this graph's tiles (xs_pick)
+  int xs_threads{0}, xs_lds_bytes{0};
   DevBuf xs_partial, xs_counters;
   int64_t n_hub_items{0};
   HubItem const* hub_items{nullptr};
@@ -1937,8 +2098,12 @@ int session_geometry(Session& s, PullPlan& plan)
   int64_t nl = s.n_local;
   // ---- launch geometry: all buckets in one grid, hubs first
   int begin = 0;
-  // timing aid: CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets (results are then wrong)
+  // timing aid (make AIDS=1): CUGRAPH_AMD_BUCKET_MASK=<bits> runs only the named buckets
+#ifdef CGA_TIMING_AIDS
   char const* mask_env = std::getenv("CUGRAPH_AMD_BUCKET_MASK");
+#else
+  char const* mask_env = nullptr;
+#endif
   int bucket_mask      = mask_env ? std::atoi(mask_env) : 0x1F;
   int const group_width[kNumBuckets] = {kThreads, 64, 16, 1, 1};
   int const block_cap[kNumBuckets]   = {4096, 3072, 3072, 2048, 2048};
@@ -1959,9 +2124,22 @@ int session_geometry(Session& s, PullPlan& plan)
   s.xs_block_begin = 0;
   s.n_xs_blocks    = 0;
   if (s.xs_on) {
+    // the kernel instantiation for this plan's tiles, and as many workgroups as are resident at
+    // once (LDS- and register-bound: asked of the runtime), capped by the work items there are
+    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl,
+                                                  plan.xs_acc_mode, plan.xs_wpe);
+    CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(ch.kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ch.lds));
+    int per_cu = 0, n_cu = 0;
+    CGA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<void const*>(ch.kern),
+                                                         ch.threads, static_cast<size_t>(ch.lds)));
+    CGA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.handle->device));
+    CGA_EXPECTS(per_cu > 0 && n_cu > 0, CUGRAPH_UNKNOWN_ERROR, "internal: xs_kernel does not fit a compute unit");
+    s.xs_kernel_fn = reinterpret_cast<void*>(ch.kern);
+    s.xs_threads   = ch.threads;
+    s.xs_lds_bytes = ch.lds;
     char const* xb = std::getenv("CUGRAPH_AMD_XS_BLOCKS");
-    // as many workgroups as are resident at once (LDS-bound): 4 of 256 threads, 2 of 512 or 1 of 1024 per CU
-    int want       = xb ? std::atoi(xb) : 1024 >> (plan.xs_row_bits - kXsRowBits);
+    int want       = xb ? std::atoi(xb) : per_cu * n_cu;
     s.n_xs_blocks  = static_cast<int>(std::min<int64_t>(
       static_cast<int64_t>(std::max(plan.xs_n_items[0], plan.xs_n_items[1])) * kXsSlices, want));
   }
@@ -2026,7 +2204,7 @@ void session_setup(Session& s, PagerankArgs const& a)
     s.x[k].alloc(static_cast<size_t>(s.x_len > 0 ? s.x_len : 1) * vb);
   }
   s.out_w.alloc(static_cast<size_t>(nl > 0 ? nl : 1) * vb);
-  s.scal.alloc(2 * sizeof(double));
+  s.scal.alloc(4 * sizeof(double));
   s.ctrl.alloc(sizeof(Ctrl));
   CGA_HIP(hipMemsetAsync(s.ctrl.p, 0, sizeof(Ctrl), stream));
   // x buffers are gathered from at every global id: start them defined
@@ -2204,10 +2382,17 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   a.num_vertices    = static_cast<ValT>(s.n_global);
   a.epsilon         = s.epsilon;
   a.personalized    = s.personalized ? 1 : 0;
+#ifdef CGA_TIMING_AIDS
   {
     char const* gm = std::getenv("CUGRAPH_AMD_GATHER_MASK");
     a.gather_mask  = gm ? static_cast<uint32_t>(std::strtoul(gm, nullptr, 0)) : 0xFFFFFFFFu;
+    a.xs.gather_mask = a.gather_mask;
+    char const* am     = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
+    a.xs.affinity_mode = am ? std::atoi(am) : 0;
+    a.xs.profile       = std::getenv("CUGRAPH_AMD_XS_PROFILE") != nullptr && !g.weights;
+    a.xs.no_atomics    = std::getenv("CUGRAPH_AMD_XS_NO_ATOMICS") != nullptr;
   }
+#endif
   a.vertex_first    = g.vertex_first;
   a.x_pos           = g.x_pos;
   if (raw_y) {  // plain SpMV for the sibling power iterations (centrality.hip)
@@ -2217,12 +2402,6 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   a.hub_items        = s.hub_items;
   a.n_hub_items      = s.n_hub_items;
   a.hub_item_partial = s.hub_item_partial.as<double>();
-  {
-    char const* am      = std::getenv("CUGRAPH_AMD_XS_AFFINITY");
-    a.xs.affinity_mode = am ? std::atoi(am) : 0;
-    bool const force_search = std::getenv("CUGRAPH_AMD_XS_SEARCH_WINDOWS") != nullptr;
-    a.xs.search_windows = (force_search || (s.xs_on && s.graph->plan->xs_n_win > kXsRegWindows)) ? 1 : 0;
-  }
   if (s.xs_on) {
     PullPlan const& plan = *s.graph->plan;
     a.xs.ent       = plan.xs_ent.as<uint32_t>();
@@ -2267,37 +2446,13 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.rec      = plan.xs_rec[region].as<int64_t>();
     a.xs.n_items  = plan.xs_n_items[region];
     a.xs.counters = s.xs_counters.as<int>() + kXsSlices * region;
-    static bool const profile = std::getenv("CUGRAPH_AMD_XS_PROFILE") != nullptr;
-    auto launch_xs = [&](auto weighted_tag, auto profile_tag) {
-      constexpr bool W  = decltype(weighted_tag)::value;
-      auto wide = [&](auto bits_tag) {
-        constexpr int RB     = decltype(bits_tag)::value;
-        constexpr int T      = kThreads << (RB - kXsRowBits);
-        constexpr size_t lds = sizeof(double) << RB;
-        auto kern = xs_kernel<OffT, ValT, W, T, RB, decltype(profile_tag)::value>;
-        static bool const raised = [&] {
-          return hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds)) == hipSuccess;
-        }();
-        CGA_EXPECTS(raised, CUGRAPH_UNKNOWN_ERROR, "internal: cannot reserve the LDS of a wide XS tile");
-        hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(T), lds, stream, a);
-      };
-      if (a.xs.row_bits == 14) return wide(std::integral_constant<int, 14>{});
-      if (a.xs.row_bits == 13) return wide(std::integral_constant<int, 13>{});
-      constexpr size_t lds = sizeof(double) << kXsRowBits;
-      auto kern = xs_kernel<OffT, ValT, W, kThreads, kXsRowBits, decltype(profile_tag)::value>;
-      hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(kThreads), lds, stream, a);
-    };
-    if (profile && !g.weights) {
-      launch_xs(std::false_type{}, std::true_type{});
-      if (s.enqueued == 3)
-        hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, std::min(s.n_xs_blocks, 1024));
-    } else if (g.weights) {
-      launch_xs(std::true_type{}, std::false_type{});
-    } else {
-      launch_xs(std::false_type{}, std::false_type{});
-    }
+    XsLaunch<ValT> xl{a.xs, a.x_cur, a.scal, a.ctrl, a.epsilon};
+    auto kern = reinterpret_cast<void (*)(XsLaunch<ValT>)>(s.xs_kernel_fn);
+    hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(s.xs_threads), s.xs_lds_bytes, stream, xl);
+#ifdef CGA_TIMING_AIDS
+    if (a.xs.profile && s.enqueued == 3)
+      hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, std::min(s.n_xs_blocks, 1024));
+#endif
   }
   if (phase == 0) {
     CGA_HIP(hipGetLastError());
@@ -2569,7 +2724,7 @@ Session* spmv_session_create(Handle const& h, Graph& g)
     s->x[0].alloc(static_cast<size_t>(s->x_len) * (s->f64 ? 8 : 4));
     CGA_HIP(hipMemsetAsync(s->x[0].p, 0, s->x[0].bytes, h.stream));
   }
-  s->scal.alloc(2 * sizeof(double));
+  s->scal.alloc(4 * sizeof(double));
   s->ctrl.alloc(sizeof(Ctrl));
   double never[2] = {0.0, 1e300};  // "previous delta" that never passes the stop check
   CGA_HIP(hipMemsetAsync(s->ctrl.p, 0, sizeof(Ctrl), h.stream));

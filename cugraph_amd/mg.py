@@ -491,7 +491,12 @@ class MGPagerank:
         """The scalars first (every kernel of the next iteration tests them), then the all-gathers,
         not waited for: one handle per region."""
         x_full, scal = sess.inner.exchange_buffers()
-        _dist().all_reduce(scal, group=self.group)
+        # scal[2:4]: this rank's {dangling mass, L1 delta}; their sum over the ranks goes to scal[0:2],
+        # which the next iteration's kernels read.  An iteration skipped after the stop leaves
+        # scal[2:4] alone, so summing again gives the same scal[0:2] (never P times the last one).
+        total = scal[2:4].clone()
+        _dist().all_reduce(total, group=self.group)
+        scal[0:2].copy_(total)
         if self.regions is None:
             return (all_gather_region_async(x_full[:self.slot_chunk * self.world], self.slot_chunk, self.rank,
                                             self.world, self.group),)

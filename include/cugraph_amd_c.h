@@ -417,7 +417,10 @@ cugraph_error_code_t cugraph_amd_pagerank_session_timed_iterate(
  * vector and (b) all-reduce the two scalars, both in place on the handle's stream order:
  *   *x_full  : FLOAT32/64 view of num_global_vertices elements, the vector the NEXT iteration
  *              gathers from; this rank has just written [vertex_first, vertex_last) of it;
- *   *scalars : FLOAT64 view of 2 elements {dangling mass, L1 delta} (local sums).
+ *   *scalars : FLOAT64 view of 4 elements: [0..1] {dangling mass, L1 delta} as the next iteration's
+ *              kernels read them, [2..3] the same two sums as this rank's last executed iteration
+ *              produced them.  A multi-GPU driver sums [2..3] over the ranks INTO [0..1]; an
+ *              iteration skipped after the stop leaves [2..3] unchanged, so the sum is idempotent.
  * Caller frees both views. */
 cugraph_error_code_t cugraph_amd_pagerank_session_exchange_buffers(
   cugraph_amd_pagerank_session_t* session, cugraph_type_erased_device_array_view_t** x_full,

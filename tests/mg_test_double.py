@@ -52,13 +52,14 @@ class _Session:
             self.pers = np.zeros(nl)
             np.add.at(self.pers, pers_v.numpy() - g.first, pers_x.numpy())  # already normalised
         self.x = [torch.zeros(g.slots, dtype=torch.float64) for _ in range(2)]
-        self.scal = torch.zeros(2, dtype=torch.float64)
+        # [0:2] what the next iteration reads (summed over the ranks by the driver), [2:4] this rank's own
+        self.scal = torch.zeros(4, dtype=torch.float64)
         self.enqueued, self.iters, self.done = 0, 0, False
         dang = self.out_w == 0
         xs = np.where(dang, self.pr, self.pr / np.where(dang, 1.0, self.out_w))
         self.x[0][g.x_pos[self.wr]] = torch.from_numpy(xs[self.wr])
-        self.scal[0] = float(self.pr[dang].sum())
-        self.scal[1] = 1e300
+        self.scal[0] = self.scal[2] = float(self.pr[dang].sum())
+        self.scal[1] = self.scal[3] = 1e300
 
     def iterate(self, n=1):
         g = self.g
@@ -79,8 +80,8 @@ class _Session:
             if self.pers is not None:
                 pr = pr + teleport * self.pers
             dang = self.out_w == 0
-            self.scal[1] = float(np.abs(pr - self.pr).sum())
-            self.scal[0] = float(pr[dang].sum())
+            self.scal[1] = self.scal[3] = float(np.abs(pr - self.pr).sum())
+            self.scal[0] = self.scal[2] = float(pr[dang].sum())
             xs = np.where(dang, pr, pr / np.where(dang, 1.0, self.out_w))
             self.x[nxt][g.x_pos[self.wr]] = torch.from_numpy(xs[self.wr])
             self.pr = pr

@@ -60,12 +60,14 @@ def _worker(rank, world, port, case, out_dir):
                 pers = (pers[0][:0], pers[1][:0])
         sess = drv.session(alpha=case.get("alpha", 0.85), epsilon=case["eps"], nstart=nstart, personalization=pers,
                            sharded=bool(case.get("sharded")))
-        iters, stopped, _ = drv.run_to_convergence(sess, case["max_iter"], check_every=case["check"])
+        iters, stopped, delta = drv.run_to_convergence(sess, case["max_iter"], check_every=case["check"])
+        dangling = sess.inner.status()[3]
         full, it2, conv = drv.gathered_result(sess, case["max_iter"])
         verts, vals, _, _ = drv.result(sess, case["max_iter"])
         assert verts.tolist() == list(range(first, last)) and len(vals) == last - first
         np.save(os.path.join(out_dir, f"r{rank}.npy"), full.numpy())
-        np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([iters, it2, int(stopped), int(conv)]))
+        np.save(os.path.join(out_dir, f"meta{rank}.npy"),
+                np.array([iters, it2, int(stopped), int(conv), delta, dangling], dtype=np.float64))
     finally:
         dist.destroy_process_group()
 
@@ -138,6 +140,23 @@ def test_mg_personalization_nstart_and_nonconvergence(sharded, tmp_path):
     assert o_it == 4 and not o_conv
     for f, m in zip(fulls, metas):
         assert m[0] == 4 and not bool(m[3])
+        assert np.max(np.abs(f - o_pr)) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mg_scalars_after_a_stop_inside_a_batch(world, tmp_path):
+    """The stop lands inside a batch of 7 iterations: the skipped iterations of the batch still run
+    the collectives, which must leave the reported L1 delta and dangling mass what the converging
+    iteration made them (they were once multiplied by the world size per skipped iteration)."""
+    case = _rmat_case(9, False, check=7)
+    fulls, metas = _run(world, case, tmp_path)
+    o_pr, o_it, o_conv = _oracle(case)
+    assert o_it % 7 not in (0, 6), "pick another batch size: the stop must land inside a batch"
+    dang = float(o_pr[np.bincount(case["src"], minlength=case["nv"]) == 0].sum())
+    for f, m in zip(fulls, metas):
+        assert m[0] == o_it and bool(m[2])
+        assert 0.0 < m[4] < case["eps"]
+        assert abs(m[5] - dang) < 1e-9
         assert np.max(np.abs(f - o_pr)) < 1e-12
 
 
