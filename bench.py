@@ -2,6 +2,7 @@
 """bench.py -- PageRank iteration throughput on synthetic R-MAT (BASELINE.json's metric).
 
     python bench.py --gpus 1 --steps K --warmup W            (one process)
+    python bench.py --gpus N --steps K --warmup W            (starts its N ranks itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE PageRank iteration over the whole graph (pull SpMV with the fused rank update,
@@ -40,7 +41,31 @@ def parse():
                    help="run the multi-GPU driver (and its collectives) even with one rank")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-convergence", action="store_true")
+    p.add_argument("--no-extra-configs", action="store_true",
+                   help="skip BASELINE configs C2 (scale 22) and C3 (scale 24 fp64 weighted personalized)")
+    p.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                   help="gloo: CPU ranks, only with --engine test-double (a rehearsal of the launcher and driver)")
+    p.add_argument("--engine", default="hip", choices=("hip", "test-double"),
+                   help="test-double: the numpy stand-in of tests/mg_test_double.py instead of the HIP library; "
+                        "measures nothing -- it exists so that the multi-rank launch path can be run without GPUs")
     return p.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of THIS process
+    (which has not touched the GPU) through torch.distributed.run, pass their output through and
+    exit with their status.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def _graph_to_host(graph):
@@ -158,6 +183,117 @@ def other_cpu_baselines(args, handle):
     return out
 
 
+def extra_configs(args, handle):
+    """BASELINE.json's other single-GPU configurations as driver-timed numbers beside the headline
+    one: C2 = R-MAT scale 22 unweighted fp32, C3 = scale 24 fp64 weighted with a 1000-vertex
+    personalization (natural vertex ids, weights from stream seed + 1, first 1000 of a
+    seeded permutation with U(0,1) values).  Each: 3 warm-up + 10 event-timed iterations."""
+    import torch
+
+    from cugraph_amd import generators, pylibcugraph as plc
+    from cugraph_amd.session import PagerankSession
+
+    out = {}
+    for name, scale, weighted in (("C2_scale22_fp32_unweighted", 22, False),
+                                  ("C3_scale24_fp64_weighted_personalized_1k", 24, True)):
+        try:
+            nv, ne = 1 << scale, args.edge_factor << scale
+            src, dst = generators.rmat(handle, scale, ne, seed=args.seed, scramble_vertex_ids=False)
+            w = generators.rmat_weights(handle, ne, seed=args.seed + 1, dtype=torch.float64) if weighted else None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g = plc.SGGraph(handle, plc.GraphProperties(is_multigraph=True), src, dst, w, store_transposed=True,
+                            renumber=True, vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+            torch.cuda.synchronize()
+            t_csc = time.perf_counter() - t0
+            del src, dst, w
+            kw = {}
+            if weighted:
+                gen = torch.Generator(device="cpu").manual_seed(7)
+                kw = dict(personalization_vertices=torch.randperm(nv, generator=gen)[:1000].to(torch.int32).cuda(),
+                          personalization_values=torch.rand(1000, generator=gen, dtype=torch.float64).cuda())
+            t0 = time.perf_counter()
+            s = PagerankSession(handle, g, alpha=0.85, epsilon=0.0, **kw)
+            torch.cuda.synchronize()
+            t_plan = time.perf_counter() - t0
+            s.iterate(3)
+            it_ms, k_ms = s.timed_iterate(10)
+            info = s.info()
+            it, km = float(it_ms.mean()), float(k_ms.mean())
+            ach = info["dominant_kernel_bytes"] / (km * 1e-3) / 1e9
+            out[name] = {
+                "workload": f"R-MAT scale {scale} ef {args.edge_factor}, natural ids, "
+                            + ("fp64 weighted, 1000-vertex personalization" if weighted else "fp32 unweighted"),
+                "dtype": "f64" if weighted else "f32",
+                "ms_per_step": it, "value": ne / (it * 1e-3) / 1e9, "unit": "GTEPS",
+                "algorithmic_GBps_whole_iteration": info["bytes_per_iteration"] / (it * 1e-3) / 1e9,
+                "roofline": {"bound": "hbm", "kernel": "xs_kernel" if info["mid_degree_vertices"] else "spmv_kernel",
+                             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                             "traffic": None, "algorithmic_bytes_per_launch": info["dominant_kernel_bytes"],
+                             "kernel_ms_avg": km},
+                "graph_build": {"coo_to_csc_s": t_csc, "plan_build_s": t_plan},
+            }
+            del s, g
+            torch.cuda.empty_cache()
+        except Exception as exc:  # a reported extra must never cost the bench line
+            out[name] = {"error": repr(exc)}
+    return out
+
+
+def main_test_double(args):
+    """Rehearsal of the multi-rank path without GPUs: the same launcher, process group, driver
+    (cugraph_amd.mg: partition, edge routing, collectives, stop rule) and JSON line, with the numpy
+    stand-in of tests/mg_test_double.py (test infrastructure) as the local engine.  The line says so
+    ("engine": "test-double"): its numbers measure nothing."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from cugraph_amd import mg as mgmod
+    from mg_test_double import OracleEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scale = min(args.scale, 12)
+    nv, ne = 1 << scale, args.edge_factor << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=args.seed, scramble=bool(args.scramble))
+    sel = np.arange(ne) % world == rank
+    drv = mgmod.MGPagerank.from_edges(OracleEngine(rank, world), torch.from_numpy(src[sel].astype(np.int64)),
+                                      torch.from_numpy(dst[sel].astype(np.int64)), None, nv, rank=rank, world=world)
+    drv.always_exchange = True
+    sess = drv.session(alpha=0.85, epsilon=0.0)
+    drv.iterate(sess, args.warmup)
+    dist.barrier()
+    t0 = time.perf_counter()
+    drv.iterate(sess, args.steps)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    full, iters, _ = drv.gathered_result(sess, args.steps + args.warmup + 1)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "PageRank GTEPS/iter + achieved HBM GB/s, R-MAT scale 26 at 1/2/4/8 MI355X",
+            "value": ne * args.steps / elapsed / 1e9, "unit": "GTEPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "engine": "test-double",
+            "config": {"workload": f"launcher rehearsal on CPU ranks over gloo: R-MAT scale {scale}, numpy stand-in "
+                                   "engine (tests/mg_test_double.py); not a measurement"},
+            "iterations": int(iters), "rank_sum": float(full.sum()),
+        }), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def pmc_traffic(scale, ef, n_gpus):
     """HBM bytes per xs_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
     None when they do not describe this workload.  bench.py cannot run under the profiler itself."""
@@ -174,6 +310,12 @@ def pmc_traffic(scale, ef, n_gpus):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.engine == "test-double":
+        return main_test_double(args)
+    if args.backend != "nccl":
+        raise SystemExit("--backend gloo runs CPU ranks: it needs --engine test-double")
     # libraries (RCCL's banner, ...) write to the C-level stdout: keep fd 1 for the one JSON line
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -183,8 +325,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: let bench.py start its ranks itself "
+                         f"(no WORLD_SIZE in the environment) or launch {args.gpus} ranks")
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if n_dev < world:
+        raise SystemExit(f"bench.py --gpus {world} needs {world} devices, one per rank: this machine has {n_dev}")
     torch.cuda.set_device(local_rank if world > 1 else 0)
 
     from cugraph_amd import generators, pylibcugraph as plc
@@ -238,13 +384,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- timed region: K iterations, epsilon = 0 so that none is skipped
+    # ---------------- the first session on a graph builds its pull plan (degree-sorted copy of a
+    # renumber=False graph, compact source slots, XS tiles), once per graph: timed on its own
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     if not use_mg:
         sess = PagerankSession(handle, graph, alpha=0.85, epsilon=0.0)
         step = lambda n: sess.iterate(n)  # noqa: E731
     else:
         sess = mg.session(alpha=0.85, epsilon=0.0)
         step = lambda n: mg.iterate(sess, n)  # noqa: E731
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+    # ---------------- timed region: K iterations, epsilon = 0 so that none is skipped
     step(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -298,7 +450,9 @@ def main():
             s2 = mg.session(alpha=0.85, epsilon=eps)
             it, stopped, delta = mg.run_to_convergence(s2, 500)
         barrier()
-        conv = {"iterations": it, "converged": bool(stopped), "seconds": time.perf_counter() - t0,
+        dt = time.perf_counter() - t0
+        conv = {"iterations": it, "converged": bool(stopped), "seconds": dt,
+                "seconds_including_build": t_csc + t_plan + dt,
                 "l1_delta": delta, "epsilon": eps,
                 "note": "NetworkX's stop rule, sum|dx| < N*tol: at N = 2^26 the threshold is 0.67, so the "
                         "first iteration already meets it (networkx.pagerank stops there too)"}
@@ -317,8 +471,13 @@ def main():
             s3 = mg.session(alpha=0.85, epsilon=eps_abs)
             it, stopped, delta = mg.run_to_convergence(s3, 500, check_every=8)
         barrier()
-        conv_abs = {"iterations": it, "converged": bool(stopped), "seconds": time.perf_counter() - t0,
-                    "l1_delta": delta, "epsilon": eps_abs}
+        dt = time.perf_counter() - t0
+        conv_abs = {"iterations": it, "converged": bool(stopped), "seconds": dt,
+                    "seconds_including_build": t_csc + t_plan + dt,
+                    "l1_delta": delta, "epsilon": eps_abs,
+                    "note": "seconds: session set-up + iterations on a graph whose plan exists; "
+                            "seconds_including_build adds the one-off COO->CSC build and plan build "
+                            "(SURVEY 8d: time to convergence = build + iterations)"}
         del s3
 
     out = {
@@ -341,11 +500,15 @@ def main():
             "partition": "single GPU" if not use_mg else f"1D by destination over {world} GPUs",
             "renumber": bool(args.renumber) if not use_mg else False,
         },
-        "achieved_hbm_GBps_whole_iteration": info["bytes_per_iteration"] * (world if world > 1 else 1)
+        # ALGORITHMIC bytes of one iteration (E*4 + (V+1)*4 + 5*V*4) over its time: what the
+        # metric calls achieved GB/s.  Not bytes moved: dead rows are not even visited, gathers re-read
+        # lines (roofline.traffic has the counter bytes of the dominant kernel).
+        "algorithmic_GBps_whole_iteration": info["bytes_per_iteration"] * (world if world > 1 else 1)
         / (ms_per_step * 1e-3) / 1e9,
         "roofline": roofline,
-        "graph_build": {"generate_s": t_gen, "coo_to_csc_s": t_csc,
-                        "edges_per_s": ne / t_csc if t_csc > 0 else None},
+        "graph_build": {"generate_s": t_gen, "coo_to_csc_s": t_csc, "plan_build_s": t_plan,
+                        "edges_per_s": ne / t_csc if t_csc > 0 else None,
+                        "edges_per_s_including_plan": ne / (t_csc + t_plan) if t_csc + t_plan > 0 else None},
         "time_to_convergence": conv,
         "time_to_convergence_abs_eps": conv_abs,
         "buckets": {k: info[k] for k in ("low_degree_vertices", "mid_degree_vertices", "hub_vertices",
@@ -353,6 +516,10 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sess = None
+        graph = None
+        torch.cuda.empty_cache()
+        if not args.no_extra_configs:
+            out["other_configs"] = extra_configs(args, handle)
         out["cpu_baseline"] = cpu_baseline(args, handle, props)
         out["cpu_baselines_networkx_scipy"] = other_cpu_baselines(args, handle)
     elif rank == 0:

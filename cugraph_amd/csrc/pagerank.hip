@@ -54,7 +54,6 @@ constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longe
 constexpr int kXsRowBits      = 12;
 constexpr int kXsRowBitsMax   = 14;
 constexpr int kXsMinDegree    = kLowDegreeMax + 1;
-constexpr int64_t kXsLongRow = 4096;  // rows with more edges than this keep fp64 accumulators (xs_acc_bytes mode 2)
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
 // a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile
@@ -532,37 +531,44 @@ struct XsLaunch {
   double epsilon;
 };
 
-// accumulators of a tile, per workgroup.  ACCMODE 0: fp64, 2^ROWBITS of them.  1: fp32.  2: the
-// same bytes hold 2^ROWBITS fp32 accumulators for a tile with more than 2^(ROWBITS-1) rows -- the
-// low-degree tiles, whose row sums have few terms -- and 2^(ROWBITS-1) fp64 ones for every other
-// tile (the long rows: the first tiles of a degree-sorted graph stop at kXsTileEdges edges, not at
-// the row limit).
-__host__ __device__ constexpr int xs_acc_bytes(int row_bits, int acc_mode)
-{
-  return acc_mode == 0 ? (8 << row_bits) : (4 << row_bits);
-}
-
 #ifdef CGA_TIMING_AIDS
-// per-workgroup time in set-up / passes / write-back (make AIDS=1; CUGRAPH_AMD_XS_PROFILE=1)
+// per-workgroup times (make AIDS=1; CUGRAPH_AMD_XS_PROFILE=1)
 __device__ unsigned long long xs_prof_buf[1024 * 8];
 #define CGA_XSP(stmt) do { if (a.xs.profile) { stmt; } } while (0)
 #else
 #define CGA_XSP(stmt) do { } while (0)
 #endif
 
-// WPE: waves per SIMD the register allocation must allow (THREADS / 256 = one workgroup per CU)
-template <typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EPL, int ACCMODE, int WPE = THREADS / 256>
-__global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
+typedef double v2f64_t __attribute__((ext_vector_type(2)));
+
+// wait for this wave's LDS operations, then the workgroup barrier: unlike __syncthreads() it does
+// not wait for the wave's global stores (the partials just written need not have landed)
+__device__ inline void lds_barrier()
 {
-  static_assert(ACCMODE == 0 || std::is_same<ValT, float>::value, "fp32 accumulators: fp32 graphs only");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One workgroup pulls work items (pieces of (tile, slice) units) from the queue of the XCD it runs
+// on.  Inside an item the unit of work is a WAVE pass: 64 * EPL consecutive entries, entry e of
+// lane l at position e * 64 + l, so that the 64 lanes of one gather instruction hold 64
+// consecutive entries (ascending sources: few cache lines per instruction).  Waves CLAIM their
+// passes from a counter in LDS instead of owning a fixed share of every pass: with fixed shares
+// the waves of a workgroup drift apart (the older waves win the issue arbitration and run many
+// passes ahead), and at the end of every item the early ones idle at the barrier -- wave 0 for
+// 39 % of the kernel (profiles/r2_xs_waves.md).  With claims all waves reach the end of an item
+// within one wave pass of each other.  Each wave software-pipelines its own passes: the entries
+// of its next pass are requested right after the gathers of the current one were issued.
+template <typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EPL>
+__global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
+{
   constexpr int kLowBits       = 32 - ROWBITS;
   constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
-  constexpr uint32_t kPass     = THREADS * EPL;  // entries per pass of the workgroup
-  constexpr int kAccBytes      = xs_acc_bytes(ROWBITS, ACCMODE);
+  constexpr uint32_t kPass     = THREADS * EPL;  // granule of a piece's share of its unit (xs_records_kernel)
+  constexpr uint32_t kWavePass = 64 * EPL;       // entries of one wave pass
   extern __shared__ double xs_lds[];
-  double* const acc64 = xs_lds;
-  float* const acc32  = reinterpret_cast<float*>(xs_lds);
+  double* const acc = xs_lds;  // [2^ROWBITS]
   __shared__ int64_t s_rec[2][kXsRecWords];
+  __shared__ unsigned int s_claim;  // next wave pass of the current item
   if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
   XsArgs<ValT> const& xs = a.xs;
   int const tid  = threadIdx.x;
@@ -572,13 +578,17 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
   int const my  = xs.affinity_mode == 0   ? static_cast<int>(xcc_id() & (kXsSlices - 1))
                   : xs.affinity_mode == 1 ? static_cast<int>(blockIdx.x & (kXsSlices - 1))
                                           : static_cast<int>((blockIdx.x >> 3) & (kXsSlices - 1));
-  unsigned long long pt_setup = 0, pt_pass = 0, pt_wb = 0, pt_n = 0, pt_stolen = 0, pt_a = 0, pt_b = 0;
+  unsigned long long pt_bound = 0, pt_n = 0, pt_stolen = 0, pt_a = 0, pt_b1 = 0, pt_wbk = 0, pt_c = 0;
   unsigned long long const pt_t0 = wall_clock64();
 #else
   int const my = static_cast<int>(xcc_id() & (kXsSlices - 1));
 #endif
-  // the accumulators start at zero (all-zero bytes: either type) and every write-back leaves them so
-  for (int i = tid; i < kAccBytes / 4; i += THREADS) acc32[i] = 0.f;
+  // the accumulators start at zero and every write-back leaves them at zero
+  for (int i = tid; i < (1 << ROWBITS); i += THREADS) acc[i] = 0.0;
+  if (tid == 0) s_claim = 0;
+  int const shift         = xs.slice_shift;
+  uint32_t const low_mask = (1u << shift) - 1u;
+  int const n_win         = xs.n_win;
   // record of queue item q of slice k (the first wave, 8 bytes a lane); -1: queue empty
   auto load_record = [&](int k, int q) -> int64_t {
     int64_t r = -1;
@@ -586,49 +596,62 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
       r = xs.rec[(static_cast<int64_t>(k) * xs.n_items + q) * kXsRecWords + lane];
     return r;
   };
+  // next wave pass of the item, the same value in every lane (one LDS atomic per wave and pass)
+  auto claim = [&]() -> uint32_t {
+    unsigned int c = 0;
+    if (lane == 0) c = atomicAdd(&s_claim, 1u);
+    return __builtin_amdgcn_readfirstlane(c);
+  };
   int buf = 0;
   for (int rot = 0; rot < kXsSlices; ++rot) {
     int const k = (my + rot) & (kXsSlices - 1);
-    CGA_XSP(pt_a = wall_clock64());
-    // the first item of a queue is fetched on the spot, every later one during the item before it
+    uint32_t const kbits = static_cast<uint32_t>(k) << shift;
+    // The first wave keeps the queue three items ahead of the item being worked on, so that no
+    // round trip of the queue is ever waited for, however short the items are: in LDS the records
+    // of the current item and the next, in registers the record after those (requested one
+    // boundary ago) and the queue position of the one after that (popped one boundary ago).
+    // The first items of a queue are fetched on the spot.
+    int q_popped      = 0;
+    int64_t r_loading = -1;
     if (wave0) {
-      int q = 0;
-      if (lane == 0) q = atomicAdd(&xs.counters[k], 1);
-      q         = __shfl(q, 0);
-      int64_t r = load_record(k, q);
-      if (lane < kXsRecWords) s_rec[buf][lane] = r;
+      int q[4] = {0, 0, 0, 0};
+      if (lane == 0) {
+        int const q0 = atomicAdd(&xs.counters[k], 4);
+        q[0] = q0; q[1] = q0 + 1; q[2] = q0 + 2; q[3] = q0 + 3;
+      }
+      int64_t const r0 = load_record(k, __shfl(q[0], 0)), r1 = load_record(k, __shfl(q[1], 0));
+      r_loading = load_record(k, __shfl(q[2], 0));
+      q_popped  = q[3];
+      if (lane < kXsRecWords) {
+        s_rec[buf][lane]     = r0;
+        s_rec[buf ^ 1][lane] = r1;
+      }
     }
     __syncthreads();
     while (true) {
       int64_t const* rec = s_rec[buf];
       int64_t const head = uniform64(rec[0]);  // tile | piece << 32 | pieces << 40
       if (head < 0) break;
+      CGA_XSP(pt_n++; pt_stolen += rot != 0);
       int const t       = static_cast<int>(head & 0xffffffff);
       uint32_t const piece = static_cast<uint32_t>(head >> 32) & 0xffu;
       uint32_t const n_pc  = static_cast<uint32_t>(head >> 40) & 0xffu;
       int const rows    = static_cast<int>(uniform64(rec[1]) >> 32);
       ValT* const out   = xs.partial + uniform64(rec[2]);
-      // the next item is asked for two passes before this one ends (not earlier: an item reserved
-      // by a busy workgroup is an item an idle one cannot take) and its record one pass later, so
-      // neither round trip is waited for; the record is parked in LDS after the last pass
-      int q_next = 0;
       // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
       // so every lane keeps the 4 row sums in registers and the block reduces them at the end
       bool const few = rows <= 4;
-      bool const use32 = ACCMODE == 1 || (ACCMODE == 2 && rows > (1 << (ROWBITS - 1)));
       double racc[4] = {0.0, 0.0, 0.0, 0.0};
-      int const shift = xs.slice_shift;
       // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
       // from its position.  bound(w): first position of window w relative to the aligned start
       // (0 for a window that starts before this item's entries -- an item can be the tail of a
       // unit: the second region of a partitioned graph --, 2^32 - 1 for windows past the last).
-      int64_t const u0    = ((int64_t)t * kXsSlices + k) * xs.n_win;
+      int64_t const u0    = ((int64_t)t * kXsSlices + k) * n_win;
       int64_t const beg   = uniform64(rec[3]);
       int64_t const end   = uniform64(rec[4]);
       int64_t const abeg  = beg & ~int64_t(3);
       uint32_t const rbeg = static_cast<uint32_t>(beg - abeg);
       uint32_t const rend = static_cast<uint32_t>(end - abeg);
-      int const n_win = xs.n_win;
       auto bound = [&](int w) -> uint32_t {
         if (w <= 0) return 0u;
         if (w >= n_win) return 0xFFFFFFFFu;
@@ -637,13 +660,14 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
         int64_t const d = s - abeg;
         return d > 0xFFFFFFFELL ? 0xFFFFFFFFu : d < 0 ? 0u : static_cast<uint32_t>(d);
       };
-      uint32_t const low_mask = (1u << shift) - 1u;
-      // this piece's share of the unit's passes
+      // this piece's share of the unit, in wave passes
       uint32_t const n_pass = (rend + kPass - 1) / kPass;
       uint32_t const pb_lo  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * piece / n_pc) * kPass;
       uint32_t const pb_hi  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * (piece + 1) / n_pc) * kPass;
+      uint32_t const n_wp   = (pb_hi - pb_lo) / kWavePass;
       // window of the piece's first entry: the last one that starts at or before it (the starts
-      // ascend; empty windows share a start with their successor)
+      // ascend; empty windows share a start with their successor).  A wave's passes ascend, so
+      // its window only ever moves forward from here.
       int w_cur = 0;
       {
         uint32_t const p0 = pb_lo > rbeg ? pb_lo : rbeg;
@@ -655,35 +679,30 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
         w_cur = lo;
       }
       uint32_t nb = bound(w_cur + 1);  // where the next window starts
-      // One pass of the workgroup covers THREADS * EPL entries, EPL per lane; entry e of lane tid is
-      // pb + e * THREADS + tid, so that the 64 lanes of one gather instruction hold 64 CONSECUTIVE
-      // entries (ascending sources: few cache lines per instruction).  The loop is software
-      // pipelined: the entries of pass i+1 are requested right after the gathers of pass i were
-      // issued.  Loads carry no predicates (a branch around a load defeats the compiler's vmcnt
-      // bookkeeping): positions past the unit's end are clamped to its last entry and ignored.
-      // FAST: all entries of the pass exist and lie in one window (decided on uniform values).
+      // Loads carry no predicates (a branch around a load defeats the compiler's vmcnt
+      // bookkeeping): positions past the unit's end are clamped to its last entry and dropped.
       uint32_t const q_last = (rend > 0 ? rend : 1u) - 1u;
       uint32_t en[EPL];
       ValT w[EPL];
       auto fetch = [&](uint32_t pb, uint32_t* en_out, ValT* w_out) {
-        uint32_t const pos = pb + static_cast<uint32_t>(tid);
+        uint32_t const pos = pb + static_cast<uint32_t>(lane);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          uint32_t q = pos + e * THREADS;
+          uint32_t q = pos + e * 64;
           q          = q < q_last ? q : q_last;
           en_out[e]  = __builtin_nontemporal_load(xs.ent + abeg + q);
           if constexpr (WEIGHTED) w_out[e] = __builtin_nontemporal_load(xs.w + abeg + q);
         }
       };
-      auto pass = [&](auto fast_tag, auto a32_tag, uint32_t pb, int w_lo, int w_hi) {
+      // FAST: all entries of the pass exist and lie in one window (decided on uniform values)
+      auto pass = [&](auto fast_tag, uint32_t pb, uint32_t pb_next, bool have_next, int w_lo, int w_hi) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        constexpr bool A32  = decltype(a32_tag)::value;
-        uint32_t const pos = pb + static_cast<uint32_t>(tid);
+        uint32_t const pos = pb + static_cast<uint32_t>(lane);
         bool p[EPL];
         uint32_t wn[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          uint32_t q = pos + e * THREADS;
+          uint32_t q = pos + e * 64;
           p[e]       = FAST || (q >= rbeg && q < rend);
           wn[e]      = static_cast<uint32_t>(w_lo);
         }
@@ -692,19 +711,22 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
           for (int wi = w_lo + 1; wi <= w_hi; ++wi) {
             uint32_t const b = bound(wi);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) wn[e] += pos + e * THREADS >= b ? 1u : 0u;
+            for (int e = 0; e < EPL; ++e) wn[e] += pos + e * 64 >= b ? 1u : 0u;
           }
         }
         ValT xv[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           uint32_t const loc = (wn[e] << kLowBits) | (en[e] >> ROWBITS);  // slice-local source position
-          uint32_t gi = ((loc & ~low_mask) << 3) | (static_cast<uint32_t>(k) << shift) | (loc & low_mask);
-          xv[e]       = p[e] ? a.x_cur[CGA_GMASK(a.xs, gi)] : ValT(0);
+          uint32_t gi        = ((loc & ~low_mask) << 3) | kbits | (loc & low_mask);
+          // an entry that is not the item's was clamped to the item's last one, but its window was
+          // counted from its own position: the slot may not exist.  Slot 0 always does.
+          if constexpr (!FAST) gi = p[e] ? gi : 0u;
+          xv[e] = a.x_cur[CGA_GMASK(a.xs, gi)];
         }
         uint32_t en_next[EPL];
         ValT w_next[EPL];
-        fetch(pb + kPass, en_next, w_next);
+        if (have_next) fetch(pb_next, en_next, w_next);
         if constexpr (WEIGHTED) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
@@ -722,98 +744,87 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
           ValT sum = 0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
-          if (sum == ValT(-1)) atomicAdd(&acc64[0], 1.0);
+          if (sum == ValT(-1)) atomicAdd(&acc[0], 1.0);
 #endif
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e)
-            if (p[e]) {
-              if constexpr (A32)
-                atomicAdd(&acc32[en[e] & kRowMask], static_cast<float>(xv[e]));
-              else
-                atomicAdd(&acc64[en[e] & kRowMask], static_cast<double>(xv[e]));
-            }
+            if (p[e]) atomicAdd(&acc[en[e] & kRowMask], static_cast<double>(xv[e]));
         }
+        if (have_next) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          en[e] = en_next[e];
-          if constexpr (WEIGHTED) w[e] = w_next[e];
-        }
-      };
-      CGA_XSP(pt_b = wall_clock64(); pt_setup += pt_b - pt_a; pt_n++; pt_stolen += rot != 0);
-      fetch(pb_lo, en, w);
-      int64_t r_next = -1;
-      int stage      = 0;  // 1: next item asked for, 2: its record requested
-      auto look_ahead = [&]() {
-        if (stage == 0) {
-          if (wave0 && lane == 0) q_next = atomicAdd(&xs.counters[k], 1);
-          stage = 1;
-        } else if (stage == 1) {
-          if (wave0) r_next = load_record(k, __shfl(q_next, 0));
-          stage = 2;
-        }
-      };
-      for (uint32_t pb = pb_lo; pb < pb_hi; pb += kPass) {
-        uint32_t const pe = pb + kPass;
-        if (pb >= rbeg && pe <= rend && pe <= nb) {
-          if constexpr (ACCMODE == 2) {
-            if (use32) pass(std::true_type{}, std::true_type{}, pb, w_cur, w_cur);
-            else pass(std::true_type{}, std::false_type{}, pb, w_cur, w_cur);
-          } else {
-            pass(std::true_type{}, std::integral_constant<bool, ACCMODE == 1>{}, pb, w_cur, w_cur);
+          for (int e = 0; e < EPL; ++e) {
+            en[e] = en_next[e];
+            if constexpr (WEIGHTED) w[e] = w_next[e];
           }
+        }
+      };
+      uint32_t i0 = claim(), i1 = claim();
+      if (i0 < n_wp) fetch(pb_lo + i0 * kWavePass, en, w);
+      while (i0 < n_wp) {
+        uint32_t const pb = pb_lo + i0 * kWavePass, pe = pb + kWavePass;
+        uint32_t const i2 = claim();
+        // windows that end before this pass were another wave's
+        while (nb <= pb && w_cur + 1 < n_win) {
+          ++w_cur;
+          nb = bound(w_cur + 1);
+        }
+        bool const have_next = i1 < n_wp;
+        uint32_t const pb_next = pb_lo + i1 * kWavePass;
+        if (pb >= rbeg && pe <= rend && pe <= nb) {
+          pass(std::true_type{}, pb, pb_next, have_next, w_cur, w_cur);
         } else {
           int w_hi = w_cur;
           while (nb < pe && w_hi + 1 < n_win) {  // window w_hi + 1 starts inside this pass
             ++w_hi;
             nb = bound(w_hi + 1);
           }
-          if constexpr (ACCMODE == 2) {
-            if (use32) pass(std::false_type{}, std::true_type{}, pb, w_cur, w_hi);
-            else pass(std::false_type{}, std::false_type{}, pb, w_cur, w_hi);
-          } else {
-            pass(std::false_type{}, std::integral_constant<bool, ACCMODE == 1>{}, pb, w_cur, w_hi);
-          }
+          pass(std::false_type{}, pb, pb_next, have_next, w_cur, w_hi);
           w_cur = w_hi;
         }
-        if (pb + 3 * kPass >= pb_hi) look_ahead();
+        i0 = i1;
+        i1 = i2;
       }
-      look_ahead();
-      look_ahead();
-      CGA_XSP(pt_a = wall_clock64(); pt_pass += pt_a - pt_b);
+      CGA_XSP(pt_a = wall_clock64());
       if (few) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           double v = group_sum(racc[rr], 64);
-          if (lane == 0 && rr < rows) {
-            if (use32) atomicAdd(&acc32[rr], static_cast<float>(v));
-            else atomicAdd(&acc64[rr], v);
-          }
+          if (lane == 0 && rr < rows) atomicAdd(&acc[rr], v);
         }
       }
       __syncthreads();
-      if (use32) {
-        for (int i = tid; i < rows; i += THREADS) {
-          __builtin_nontemporal_store(static_cast<ValT>(acc32[i]), out + i);
-          acc32[i] = 0.f;
-        }
-      } else {
-        for (int i = tid; i < rows; i += THREADS) {
-          __builtin_nontemporal_store(static_cast<ValT>(acc64[i]), out + i);
-          acc64[i] = 0.0;
-        }
+      CGA_XSP(pt_c = wall_clock64(); pt_b1 += pt_c - pt_a);
+      // the partials of a tile are padded to a multiple of 4 rows (build_xs): whole vectors
+      int const rows4 = (rows + 3) & ~3;
+      for (int i = tid * 4; i < rows4; i += THREADS * 4) {
+        v2f64_t const s0 = *reinterpret_cast<v2f64_t const*>(acc + i);
+        v2f64_t const s1 = *reinterpret_cast<v2f64_t const*>(acc + i + 2);
+        ValT const r4[4] = {static_cast<ValT>(s0.x), static_cast<ValT>(s0.y), static_cast<ValT>(s1.x),
+                            static_cast<ValT>(s1.y)};
+        stream_store_vals4(out + i, r4);
+        v2f64_t const z = {0.0, 0.0};
+        *reinterpret_cast<v2f64_t*>(acc + i)     = z;
+        *reinterpret_cast<v2f64_t*>(acc + i + 2) = z;
       }
-      if (wave0 && lane < kXsRecWords) s_rec[buf ^ 1][lane] = r_next;
+      CGA_XSP(pt_wbk += wall_clock64() - pt_c);
+      if (wave0) {
+        // the slot of the item that just ended takes the record two items on; the queue moves up
+        if (lane < kXsRecWords) s_rec[buf][lane] = r_loading;
+        r_loading = load_record(k, __shfl(q_popped, 0));
+        if (lane == 0) q_popped = atomicAdd(&xs.counters[k], 1);
+      }
+      if (tid == 0) s_claim = 0;
       buf ^= 1;
-      __syncthreads();
-      CGA_XSP(pt_wb += wall_clock64() - pt_a);
+      lds_barrier();
+      CGA_XSP(pt_bound += wall_clock64() - pt_a);
     }
   }
 #ifdef CGA_TIMING_AIDS
   if (xs.profile && tid == 0 && blockIdx.x < 1024) {
-    unsigned long long* o = xs_prof_buf + 8 * blockIdx.x;
-    o[0] = my; o[1] = wall_clock64() - pt_t0; o[2] = pt_setup; o[3] = pt_pass; o[4] = pt_wb; o[5] = pt_n; o[6] = pt_stolen;
-    o[7] = pt_t0;
+    unsigned long long* o8 = xs_prof_buf + 8 * blockIdx.x;
+    o8[0] = my; o8[1] = wall_clock64() - pt_t0; o8[2] = pt_bound; o8[3] = pt_n; o8[4] = pt_stolen;
+    o8[5] = pt_b1; o8[6] = pt_wbk; o8[7] = pt_t0;
   }
 #endif
 }
@@ -836,37 +847,22 @@ struct XsKernelChoice {
   int lds;
 };
 
-constexpr int xs_threads_for(int row_bits)
-{
-  return row_bits >= 14 ? 1024 : kThreads << (row_bits - kXsRowBits);
-}
+constexpr int xs_threads_for(int row_bits) { return kThreads << (row_bits - kXsRowBits); }
 
 template <typename ValT>
-XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl, int acc_mode, int wpe = 0)
+XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl)
 {
-#define CGA_XS_CASE_W(W, RB, EPL, ACC, WPE)                                                    \
-  if (weighted == W && row_bits == RB && epl == EPL && acc_mode == ACC && (wpe == WPE || (wpe == 0 && WPE == xs_threads_for(RB) / 256))) \
-    return XsKernelChoice<ValT>{xs_kernel<ValT, W, xs_threads_for(RB), RB, EPL, ACC, WPE>,     \
-                                xs_threads_for(RB), xs_acc_bytes(RB, ACC)};
-#define CGA_XS_CASE(W, RB, EPL, ACC) CGA_XS_CASE_W(W, RB, EPL, ACC, xs_threads_for(RB) / 256)
-  CGA_XS_CASE(false, 12, 8, 0)
-  CGA_XS_CASE(false, 13, 8, 0)
-  CGA_XS_CASE(false, 14, 8, 0)
-  CGA_XS_CASE(true, 12, 8, 0)
-  CGA_XS_CASE(true, 13, 8, 0)
-  CGA_XS_CASE(true, 14, 8, 0)
-  if constexpr (std::is_same<ValT, float>::value) {
-    CGA_XS_CASE(false, 14, 16, 0)
-    CGA_XS_CASE(false, 14, 8, 1)
-    CGA_XS_CASE(false, 14, 16, 1)
-    CGA_XS_CASE(false, 15, 8, 1)
-    CGA_XS_CASE(false, 15, 16, 1)
-    CGA_XS_CASE(false, 15, 8, 2)
-    CGA_XS_CASE(false, 15, 16, 2)
-    CGA_XS_CASE_W(false, 14, 8, 1, 8)  // two 64 KiB workgroups per CU
-  }
+#define CGA_XS_CASE(W, RB, EPL)                                                         \
+  if (weighted == W && row_bits == RB && epl == EPL)                                    \
+    return XsKernelChoice<ValT>{xs_kernel<ValT, W, xs_threads_for(RB), RB, EPL>,        \
+                                xs_threads_for(RB), static_cast<int>(sizeof(double)) << RB};
+  CGA_XS_CASE(false, 12, 8)
+  CGA_XS_CASE(false, 13, 8)
+  CGA_XS_CASE(false, 14, 8)
+  CGA_XS_CASE(true, 12, 8)
+  CGA_XS_CASE(true, 13, 8)
+  CGA_XS_CASE(true, 14, 8)
 #undef CGA_XS_CASE
-#undef CGA_XS_CASE_W
   throw Failure(CUGRAPH_UNKNOWN_ERROR, "internal: no xs_kernel for this tile layout");
 }
 
@@ -981,12 +977,13 @@ __global__ void xs_records_kernel(XsItem const* __restrict__ items, int n_items,
     XsItem it = items[q];
     int64_t t = it.tile, piece = it.piece, n_pc = it.pieces;
     int64_t row0 = tile_row[t], rows = tile_row[t + 1] - row0;
-    int64_t sets = (pbase[t + 1] - pbase[t]) / (rows * kXsSlices);
+    int64_t rows_pad = (rows + 3) & ~int64_t(3);  // partials of a tile: whole 4-row vectors (build_xs)
+    int64_t sets = (pbase[t + 1] - pbase[t]) / (rows_pad * kXsSlices);
     int64_t u0 = (t * kXsSlices + k) * n_win;
     int64_t* r = rec + i * kXsRecWords;
     r[0] = t | (piece << 32) | (n_pc << 40);
     r[1] = row0 | (rows << 32);
-    r[2] = pbase[t] + (k * sets + it.pset) * rows;
+    r[2] = pbase[t] + (k * sets + it.pset) * rows_pad;
     r[3] = unit_off[u0 + win_lo];
     r[4] = unit_off[u0 + win_hi];
     for (int w = 1; w < kXsRecWindows; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
@@ -1025,18 +1022,13 @@ __global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const*
 template <typename OffT>
 __global__ void xs_break_flags_kernel(OffT const* __restrict__ offsets, int64_t row_first,
                                       int64_t n_rows, int64_t e0, int64_t tile_edges, int64_t max_rows,
-                                      int64_t long_row, unsigned int* __restrict__ flags)
+                                      unsigned int* __restrict__ flags)
 {
-  // long_row > 0 (tiles whose second half of rows only has fp32 accumulators, xs_acc_bytes mode 2):
-  // while the rows are longer than that, tiles stop at half the row limit and so keep fp64 sums
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t o  = static_cast<int64_t>(offsets[row_first + i]);
-    int64_t w  = (o - e0) / tile_edges;
+    int64_t w  = (static_cast<int64_t>(offsets[row_first + i]) - e0) / tile_edges;
     int64_t wp = i == 0 ? -1 : (static_cast<int64_t>(offsets[row_first + i - 1]) - e0) / tile_edges;
-    int64_t m  = (long_row > 0 && static_cast<int64_t>(offsets[row_first + i + 1]) - o > long_row) ? max_rows / 2
-                                                                                                    : max_rows;
-    flags[i]   = (w != wp || (i % m) == 0) ? 1u : 0u;
+    flags[i]   = (w != wp || (i % max_rows) == 0) ? 1u : 0u;
   }
 }
 
@@ -1477,8 +1469,6 @@ struct PullPlan {
   int64_t xs_partial_len{0};
   int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
   int xs_epl{kXsEntriesPerLane};  // entries a lane of xs_kernel keeps in flight per pass
-  int xs_acc_mode{0};             // accumulators of a tile: see xs_acc_bytes
-  int xs_wpe{0};                  // waves per SIMD xs_kernel's registers must allow (0: one workgroup per CU)
   DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec[2], xs_pbase, xs_fin_items;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
@@ -1605,26 +1595,13 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // windows at 14 bits) 12.99 / 11.82 / 10.86.
   char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
   int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
-  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax + 1) row_bits = std::atoi(rb_env);
-  // accumulator type and entries per lane of the kernel these tiles are for (xs_pick lists what exists)
-  char const* acc_env = std::getenv("CUGRAPH_AMD_XS_ACC");
-  char const* epl_env = std::getenv("CUGRAPH_AMD_XS_EPL");
-  int acc_mode = acc_env ? std::atoi(acc_env) : 0;
-  int epl      = epl_env ? std::atoi(epl_env) : kXsEntriesPerLane;
-  if (!std::is_same<ValT, float>::value || g.weights) {
-    acc_mode = 0;
-    epl      = kXsEntriesPerLane;
-  }
-  if (acc_mode == 0 && row_bits > kXsRowBitsMax) row_bits = kXsRowBitsMax;
-  if (acc_mode == 2 && row_bits <= kXsRowBitsMax) acc_mode = 0;
-  char const* wpe_env = std::getenv("CUGRAPH_AMD_XS_WPE");
-  int const wpe = (wpe_env && acc_mode != 0 && epl == kXsEntriesPerLane) ? std::atoi(wpe_env) : 0;
-  (void)xs_pick<ValT>(g.weights != nullptr, row_bits, epl, acc_mode, wpe);  // throws if there is no such kernel
+  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
+  int const epl = kXsEntriesPerLane;  // (4: 1.94 ms, 16: 1.77 ms against 1.75 ms at scale 26)
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
                      offsets, row_first, n_rows, e0, tile_edges, int64_t(1) << row_bits,
-                     acc_mode == 2 ? kXsLongRow : int64_t(0), flags.as<unsigned int>());
+                     flags.as<unsigned int>());
   exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n_rows, pos.as<int64_t>());
   int64_t n_tiles64 = 0;
   CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
@@ -1734,13 +1711,15 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
       sets += n_pc;
     }
     int64_t const rows_t = h_row[t + 1] - h_row[t];
+    // a set of partials is padded to a multiple of 4 rows: xs_kernel writes it as 16-byte vectors
+    int64_t const rows_pad = (rows_t + 3) & ~int64_t(3);
     h_pbase[t] = plen;
-    plen += static_cast<int64_t>(kXsSlices) * sets * rows_t;
+    plen += static_cast<int64_t>(kXsSlices) * sets * rows_pad;
     for (int64_t r = 0; r < rows_t; r += kXsFinishRows) {
       h_fin.push_back(h_row[t] + r);
       h_fin.push_back(std::min<int64_t>(kXsFinishRows, rows_t - r) | static_cast<int64_t>(kXsSlices * sets) << 32);
       h_fin.push_back(h_pbase[t] + r);
-      h_fin.push_back(rows_t);
+      h_fin.push_back(rows_pad);
     }
   }
   h_pbase[n_tiles] = plen;
@@ -1776,8 +1755,6 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_slice_shift = slice_shift;
   plan.xs_row_bits  = row_bits;
   plan.xs_epl       = epl;
-  plan.xs_acc_mode  = acc_mode;
-  plan.xs_wpe       = wpe;
 }
 
 template <typename OffT>
@@ -2126,8 +2103,7 @@ int session_geometry(Session& s, PullPlan& plan)
   if (s.xs_on) {
     // the kernel instantiation for this plan's tiles, and as many workgroups as are resident at
     // once (LDS- and register-bound: asked of the runtime), capped by the work items there are
-    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl,
-                                                  plan.xs_acc_mode, plan.xs_wpe);
+    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl);
     CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(ch.kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ch.lds));
     int per_cu = 0, n_cu = 0;

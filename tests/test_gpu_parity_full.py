@@ -264,9 +264,9 @@ def test_two_regions_of_the_gathered_vector(monkeypatch):
                 if q != r:
                     bufs[q][0][lo + r * c:lo + (r + 1) * c] = piece
         if region == 1:
-            scal = sum(b[1] for b in bufs)
+            scal = sum(b[1][2:4] for b in bufs)  # every rank's own {dangling mass, L1 delta} ...
             for b in bufs:
-                b[1].copy_(scal)
+                b[1][0:2].copy_(scal)  # ... summed into what the next iteration reads
 
     exchange(0), exchange(1)
     for _ in range(100):

@@ -720,9 +720,9 @@ def test_partitioned_sessions_emulated_ranks(world, weighted, xs_tiles, monkeypa
         for r, (xf, sc) in enumerate(bufs):
             assert xf.numel() == slot_chunk * world
             x[r * slot_chunk:(r + 1) * slot_chunk] = xf[r * slot_chunk:(r + 1) * slot_chunk]
-            scal += sc
+            scal += sc[2:4]  # this rank's own {dangling mass, L1 delta}
         for xf, sc in bufs:
-            xf.copy_(x), sc.copy_(scal)
+            xf.copy_(x), sc[0:2].copy_(scal)  # what the next iteration's kernels read
 
     exchange()
     for _ in range(500):

@@ -217,3 +217,35 @@ def test_mg_random_small_graphs(seed, world, tmp_path):
         assert bool(m[3]) == o_conv and (m[0] == o_it or wgt is None)
         # (an unweighted graph's values are fp32 at the API: the lists are rounded on their way in)
         assert np.max(np.abs(f - o_pr)) < (1e-12 if wgt is not None else 1e-7)
+
+
+def _bench(*argv):
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    return subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), *argv],
+                          capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it (the driver's command): the parent
+    spawns the N ranks before anything touches a GPU and rank 0's JSON line comes out of it.
+    Rehearsed on CPU ranks over gloo with the numpy stand-in engine."""
+    import json
+
+    r = _bench("--gpus", "2", "--backend", "gloo", "--engine", "test-double", "--scale", "9", "--steps", "3",
+               "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["engine"] == "test-double"
+    assert d["iterations"] == 4 and abs(d["rank_sum"] - 1.0) < 1e-9
+
+
+def test_bench_says_what_it_needs_without_the_devices():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the devices")
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "needs 2 devices" in r.stderr and "WORLD_SIZE" not in r.stderr.split("needs 2 devices")[0][-200:]
