@@ -19,6 +19,9 @@ void session_status(Session& s, size_t* iters, bool* stopped, double* delta, dou
 CentralityResult* session_result(Session& s, size_t max_iterations);
 void session_info(Session& s, int64_t info[8]);
 void session_exchange_buffers(Session& s, void** x_full, void** scalars);
+void noalloc_setup_device(int device);
+void edgelist_source_sums_noalloc(Handle const& h, ArrayView const& src, ArrayView const* weights,
+                                  int64_t num_vertices, double* sums, long long* num_skipped);
 void session_destroy(Session* s);
 bool session_is_f64(Session& s);
 int64_t session_num_global(Session& s);
@@ -295,6 +298,11 @@ cugraph_resource_handle_t* cugraph_amd_create_resource_handle(void* hip_stream, 
     h->rank      = rank;
     h->comm_size = comm_size < 1 ? 1 : comm_size;
     if (hipGetDevice(&h->device) != hipSuccess) return nullptr;
+    try {  // the library's init call: address of this device's static scratch (noalloc.hip)
+      noalloc_setup_device(h->device);
+    } catch (Failure const&) {
+      // reported by the entry point that needs it, which tries again
+    }
     return reinterpret_cast<cugraph_resource_handle_t*>(h.release());
   } catch (...) {
     return nullptr;
@@ -664,6 +672,31 @@ cugraph_error_code_t cugraph_amd_edgelist_source_weight_sums(
     CGA_EXPECTS(out->type == FLOAT64, CUGRAPH_INVALID_INPUT, "sums must be FLOAT64");
     edgelist_source_sums(as<Handle>(handle)->stream, *s, w, static_cast<int64_t>(out->size),
                          static_cast<double*>(out->data));
+  });
+}
+
+cugraph_error_code_t cugraph_amd_edgelist_source_weight_sums_noalloc(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* weights,
+  cugraph_type_erased_device_array_view_t* sums, cugraph_type_erased_device_array_view_t* num_skipped,
+  cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto const* s = as<ArrayView>(src);
+    auto const* w = as<ArrayView>(weights);
+    auto* out     = as<ArrayView>(sums);
+    auto* skip    = as<ArrayView>(num_skipped);
+    CGA_EXPECTS(s && out, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(is_int_type(s->type), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "src must be INT32 or INT64");
+    CGA_EXPECTS(!w || (is_float_type(w->type) && w->size == s->size), CUGRAPH_INVALID_INPUT,
+                "weights must be FLOAT32/FLOAT64 with one entry per edge");
+    CGA_EXPECTS(out->type == FLOAT64, CUGRAPH_INVALID_INPUT, "sums must be FLOAT64");
+    CGA_EXPECTS(!skip || (skip->type == INT64 && skip->size >= 1), CUGRAPH_INVALID_INPUT,
+                "num_skipped must be an INT64 view of at least one element, or NULL");
+    edgelist_source_sums_noalloc(*as<Handle>(handle), *s, w, static_cast<int64_t>(out->size),
+                                 static_cast<double*>(out->data),
+                                 skip ? static_cast<long long*>(skip->data) : nullptr);
   });
 }
 

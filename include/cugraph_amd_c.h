@@ -319,6 +319,20 @@ cugraph_error_code_t cugraph_amd_edgelist_source_weight_sums(
   const cugraph_type_erased_device_array_view_t* weights,
   cugraph_type_erased_device_array_view_t* sums, cugraph_error_t** error);
 
+/* The same sums for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * The staging buffer cugraph_amd_edgelist_source_weight_sums allocates per call is a static device
+ * array here, so the call allocates nothing, copies nothing to the host and does not synchronise:
+ *   - at most 4,194,304 edges per call (CUGRAPH_INVALID_INPUT beyond that);
+ *   - ids outside [0, size of sums) cannot be reported as an error without a read-back: they are
+ *     skipped, and their number is stored to num_skipped[0] on the device (INT64 view, may be NULL);
+ *   - all calls on one GPU share the static array: calls that overlap on one GPU race. */
+cugraph_error_code_t cugraph_amd_edgelist_source_weight_sums_noalloc(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* weights,
+  cugraph_type_erased_device_array_view_t* sums, cugraph_type_erased_device_array_view_t* num_skipped,
+  cugraph_error_t** error);
+
 /* Descending in-degree order of the destinations [vertex_first, vertex_last) a rank owns, from
  * the destination ids (INT32/INT64, global) of the edges routed to it:
  *   order[new] = old - vertex_first,  rank[old - vertex_first] = new   (INT32 views, stable).
