@@ -453,13 +453,15 @@ class MGPagerank:
         C0 sources of every rank, most of all gathers), region 1 the rest; each region is P equal
         sub-chunks, so each is one all-gather, and the second can run beside the part of the
         iteration that needs only the first (MGPagerank.iterate).  Two regions cost a second set
-        of partial sums per row (one rank at scale 26: +0.2 ms per iteration), which pays once the
-        exchange is a sizeable part of the iteration: on by default from 4 ranks.
-        CUGRAPH_AMD_MG_REGIONS=0 / 1: never / whenever the layout allows."""
+        of partial sums per row (one rank at scale 26: +0.2 ms per iteration), which can only pay
+        once the exchange is a sizeable part of the iteration.  OFF by default: the overlap has
+        never run on more than one GPU (the async all-gather beside xs_kernel's phase 0 is covered
+        by emulated ranks and gloo only), so it stays an opt-in until a multi-GPU run has timed it.
+        CUGRAPH_AMD_MG_REGIONS=1: whenever the layout allows; "auto": from 4 ranks."""
         import os
 
-        mode = os.environ.get("CUGRAPH_AMD_MG_REGIONS", "auto")
-        if mode == "0" or (mode != "1" and world < 4) or not hasattr(engine, "window_slots"):
+        mode = os.environ.get("CUGRAPH_AMD_MG_REGIONS", "0")
+        if mode not in ("1", "auto") or (mode == "auto" and world < 4) or not hasattr(engine, "window_slots"):
             return None
         total = world * max_sources
         for _ in range(3):  # the window size depends on the number of slots, which the padding changes

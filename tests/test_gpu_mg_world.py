@@ -1,0 +1,36 @@
+"""The multi-GPU driver over RCCL with MORE than one rank, one process per GPU.  Skipped on a machine with
+one GPU (the boxes this repository is developed on); it fires on the first multi-GPU lease.  What it covers
+that nothing else can: the in-place all_gather_into_tensor on tensors aliasing library-owned device memory,
+the NCCL all-to-all edge shuffle, and -- with regions on -- the asynchronous all-gather of region 1 running
+beside xs_kernel's phase 0."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("regions", ["0", "1"])
+@pytest.mark.parametrize("mode", ["unweighted", "weighted"])
+def test_driver_over_rccl_with_every_gpu_of_the_machine(mode, regions):
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs")
+    n = min(n, 8)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CUGRAPH_AMD_MG_REGIONS=regions, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               CUGRAPH_AMD_XS_MIN_EDGES="65536")  # XS tiles (and their regions) also on this small graph
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(HERE, "mg_world_worker.py"), "18", mode],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])

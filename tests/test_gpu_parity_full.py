@@ -38,6 +38,17 @@ def _top_k_agree(got, want, k, tol):
     assert np.all(np.abs(want[g[diff]] - want[w[diff]]) < tol), "top-k ranking differs beyond ties"
 
 
+def _relative_bounds(got, want, nv, rel_all, rel_top):
+    """Relative error, in the style of the reference's own check (|a - b| < max(a, b) * tol,
+    cpp/tests/link_analysis/pagerank_test.cpp:338-344): on every vertex whose rank is at least the mean
+    rank 1/V (below that the max-abs bound is the tighter one) and on the top 1000."""
+    err = np.abs(got - want)
+    big = want >= 1.0 / nv
+    assert float(np.max(err[big] / want[big])) <= rel_all
+    top = np.argpartition(-want, 1000)[:1000]
+    assert float(np.max(err[top] / want[top])) <= rel_top
+
+
 def test_config1_scale22_fp32_unweighted_vs_oracle():
     import oracle
     from cugraph_amd import pylibcugraph as plc
@@ -57,6 +68,7 @@ def test_config1_scale22_fp32_unweighted_vs_oracle():
     assert conv and o_conv
     assert np.max(np.abs(r - o_pr)) <= 1e-6  # north_star: fp32 max-abs
     _top_k_agree(r, o_pr, 1000, 1e-7)
+    _relative_bounds(r, o_pr, nv, 1e-4, 2e-5)
     # a tighter epsilon, so that the comparison is not about where each side stopped
     v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, 1e-5, 500, False,
                               fail_on_nonconvergence=False)
@@ -66,6 +78,7 @@ def test_config1_scale22_fp32_unweighted_vs_oracle():
     assert conv and o_conv
     assert np.max(np.abs(r - o_pr)) <= 1e-6
     _top_k_agree(r, o_pr, 1000, 1e-7)
+    _relative_bounds(r, o_pr, nv, 1e-4, 2e-5)
 
 
 def test_config2_scale24_fp64_weighted_personalized_vs_oracle():
@@ -92,6 +105,7 @@ def test_config2_scale24_fp64_weighted_personalized_vs_oracle():
         assert r.dtype == np.float64 and o_conv
         assert np.max(np.abs(r - o_pr)) <= 1e-10  # north_star: fp64 max-abs
         _top_k_agree(r, o_pr, 1000, 1e-12)
+        _relative_bounds(r, o_pr, nv, 1e-9, 1e-10)
         assert abs(r.sum() - 1.0) < 1e-9
 
 
@@ -172,6 +186,190 @@ def test_config3_scale26_pagerank_properties(monkeypatch):
     a, b = results["xs"][0], results["buckets"][0]
     assert float((a - b).abs().max()) <= 1e-6
     assert np.allclose(results["xs"][1], results["buckets"][1], rtol=1e-5)
+
+
+def test_config3_scale26_fp32_vs_oracle():
+    """The headline configuration against the CPU oracle itself (OpenMP C restatement of the
+    reference's pagerank_reference, a few seconds per run at 1.07 G edges): absolute epsilon 1e-6,
+    about 21 iterations; same iteration count, north_star's max-abs bound, top-1000 ranking and
+    relative bounds."""
+    import oracle
+    from cugraph_amd import pylibcugraph as plc
+
+    scale = 26
+    nv = 1 << scale
+    h, g, src, dst, _ = _rmat_graph(scale)  # renumber=False: the CSC is in the caller's ids
+    del src, dst
+    off, idx, _, _ = compressed_tensors(g)
+    off, idx = off.cpu().numpy().astype(np.int64), idx.cpu().numpy()
+    eps = 1e-6
+    v, r, conv = plc.pagerank(h, g, None, None, None, None, 0.85, eps, 500, False, fail_on_nonconvergence=False)
+    assert conv and bool((v[:1000].cpu() == __import__("torch").arange(1000)).all())
+    r = r.cpu().numpy().astype(np.float64)
+    o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, None, dtype=np.float64, alpha=0.85, epsilon=eps,
+                                         max_iterations=500)
+    assert o_conv and 15 <= o_it <= 30
+    # the same number of iterations: one session run to the same epsilon
+    from cugraph_amd.session import PagerankSession
+    sess = PagerankSession(h, g, alpha=0.85, epsilon=eps)
+    it, stopped = 0, False
+    while not stopped and it < 500:
+        sess.iterate(1)
+        it, stopped, _, _ = sess.status()
+    assert it == o_it
+    assert np.max(np.abs(r - o_pr)) <= 1e-6
+    _top_k_agree(r, o_pr, 1000, 1e-7)
+    _relative_bounds(r, o_pr, nv, 1e-4, 2e-5)
+    assert abs(r.sum() - 1.0) < 1e-4
+
+
+@pytest.mark.parametrize("regions", ["0", "1"])
+def test_config3_scale26_one_rank_of_eight(regions, monkeypatch):
+    """configs[3]'s partitioned path at full size: the local graph of ONE rank of an 8-way partition
+    of the scale-26 graph (per-rank degree order, compact source slots of all ranks, with and
+    without the two regions), fed the gathered vector and scalars of iteration 3 of the single-GPU
+    run, must produce this rank's slice of iteration 4 -- ranks, local dangling mass and local L1
+    delta -- and hold as many edges as have their destination in its range."""
+    import torch
+    from cugraph_amd import pylibcugraph as plc
+    from cugraph_amd.session import PagerankSession
+    from rank_emulation import build_rank
+
+    monkeypatch.setenv("CUGRAPH_AMD_MG_REGIONS", regions)
+    scale, world, me = 26, 8, 5
+    nv = 1 << scale
+    h, g, src, dst, _ = _rmat_graph(scale)
+    ref = PagerankSession(h, g, alpha=0.85, epsilon=0.0)
+    ref.iterate(3)
+    v3, pr3, it3, _ = ref.result(100)
+    dangling3 = ref.status()[3]
+    ref.iterate(1)
+    v4, pr4, it4, _ = ref.result(100)
+    assert (it3, it4) == (3, 4) and bool((v3[:100].cpu() == torch.arange(100)).all())
+    del ref, g, v3, v4
+    torch.cuda.empty_cache()
+
+    R = build_rank(plc.ResourceHandle(rank=me, comm_size=world), plc.GraphProperties(is_multigraph=True),
+                   src, dst, nv, world, me)
+    first, last, order = R["first"], R["last"], R["order"]
+    assert (R["regions"] is not None) == (regions == "1")
+    assert R["n_local_edges"] == int(((dst >= first) & (dst < last)).sum())
+    del src, dst
+    outdeg = R["outdeg"]
+    ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
+    sess = R["engine"].make_session(
+        R["graph"], alpha=0.85, epsilon=0.0, precomputed_vertex_out_weight_vertices=ids,
+        precomputed_vertex_out_weight_sums=outdeg[first:last][order].to(torch.float32),
+        initial_guess_vertices=ids, initial_guess_values=pr3[first:last][order].contiguous())
+    info = sess.info()
+    assert info["edges"] == R["n_local_edges"] and info["mid_degree_vertices"] > 0  # XS tiles on this rank
+    # the exchange, by hand: every slot's source value of iteration 3, and its global dangling mass
+    x_full, scal = sess.exchange_buffers()
+    assert x_full.numel() == R["n_slots"]
+    x3 = pr3 / torch.clamp(outdeg, min=1).to(pr3.dtype)
+    has = R["slot_of"] >= 0
+    mine = R["x_pos"][R["x_pos"] >= 0].long()
+    own = x_full[mine].clone()
+    x_full[R["slot_of"][has].long()] = x3[has]
+    assert bool((x_full[mine] == own).all())  # what the rank wrote itself is what the others would send
+    assert abs(float(scal[2]) - float(pr3[first:last][outdeg[first:last] == 0].double().sum())) < 1e-9
+    scal[0:2].copy_(torch.tensor([dangling3, 1e300], dtype=torch.float64))
+    if regions == "1":
+        sess.iterate_phase(0), sess.iterate_phase(1)
+    else:
+        sess.iterate(1)
+    verts, vals, iters, _ = sess.result(100)
+    assert iters == 1 and bool((verts.cpu() == torch.arange(first, last)).all())
+    got = torch.empty_like(vals)
+    got[order] = vals
+    want = pr4[first:last]
+    err = (got.double() - want.double()).abs()
+    assert float(err.max()) <= 1e-8
+    assert float((err / want.double()).max()) <= 1e-5
+    _, scal = sess.exchange_buffers()
+    dang = outdeg[first:last] == 0
+    assert abs(float(scal[2]) - float(want[dang].double().sum())) <= 1e-7
+    assert abs(float(scal[3]) - float((want.double() - pr3[first:last].double()).abs().sum())) <= 1e-6
+
+
+def test_config4_scale28_build_and_three_iterations():
+    """configs[4]'s graph on ONE GPU (4.29 G edges: int64 offsets, 52 source windows per XS unit):
+    the COO -> CSC build against checksums of the edge list, then three iterations -- mass
+    conservation, a contracting L1 delta, and the first iteration of a sample of rows recomputed
+    from the CSC in plain torch fp64."""
+    import torch
+    from cugraph_amd import _capi, generators, pylibcugraph as plc
+    from cugraph_amd.session import PagerankSession
+    import ctypes
+
+    scale = 28
+    nv, ne = 1 << scale, 16 << scale
+    h = plc.ResourceHandle()
+    src, dst = generators.rmat(h, scale, ne, seed=42, scramble_vertex_ids=True)
+
+    def checksum(s, d):
+        x = s.long() * 0x9E3779B1 + d.long() * 0x85EBCA77
+        x = (x ^ (x >> 15)) * 0x2C1B3C6D
+        return int(x.sum()), int((x ^ (x >> 13)).sum())
+
+    def add(a, b):
+        return tuple((p + q) & 0xFFFFFFFFFFFFFFFF for p, q in zip(a, b))
+
+    step = 1 << 28
+    want, indeg, outdeg = (0, 0), torch.zeros(nv, dtype=torch.int32, device="cuda"), torch.zeros(nv, dtype=torch.int32, device="cuda")
+    one = torch.ones(step, dtype=torch.int32, device="cuda")
+    for b in range(0, ne, step):
+        want = add(want, checksum(src[b:b + step], dst[b:b + step]))
+        indeg.index_add_(0, dst[b:b + step].long(), one)
+        outdeg.index_add_(0, src[b:b + step].long(), one)
+    del one
+    g = plc.SGGraph(h, plc.GraphProperties(is_multigraph=True), src, dst, store_transposed=True, renumber=False,
+                    vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    del src, dst
+    torch.cuda.empty_cache()
+    info = (ctypes.c_int64 * 8)()
+    err = ctypes.c_void_p()
+    _capi.check(_capi.load().cugraph_amd_graph_info(g.c_graph_ptr, info, ctypes.byref(err)), err, "graph_info")
+    assert info[0] == nv and info[1] == ne and info[5] == 1  # offsets are int64 from 2^31 - 1 edges
+    off, idx, _, nmap = compressed_tensors(g)
+    assert off.dtype == torch.int64 and nmap is None and int(off[0]) == 0 and int(off[-1]) == ne
+    assert bool(((off[1:] - off[:-1]) == indeg.long()).all())
+    got = (0, 0)
+    for b in range(0, nv, 1 << 24):  # rows in pieces of 16 M: their edges are one slice of indices
+        e = min(b + (1 << 24), nv)
+        lo, hi = int(off[b]), int(off[e])
+        rows = torch.repeat_interleave(torch.arange(b, e, device="cuda", dtype=torch.int32), indeg[b:e].long())
+        seg = idx[lo:hi]
+        got = add(got, checksum(seg, rows))
+        first_of_row = torch.zeros(hi - lo + 1, dtype=torch.bool, device="cuda")
+        first_of_row[(off[b:e] - lo)] = True
+        assert not bool(((seg[1:] < seg[:-1]) & ~first_of_row[1:hi - lo]).any())  # sources ascend in a column
+        del rows, seg, first_of_row
+    assert got == want
+    # ---- three iterations
+    sess = PagerankSession(h, g, alpha=0.85, epsilon=0.0)
+    sinfo = sess.info()
+    assert sinfo["edges"] == ne and sinfo["mid_degree_vertices"] > 0
+    sess.iterate(1)
+    v1, r1, it1, _ = sess.result(100)
+    d1 = sess.status()[2]
+    sess.iterate(2)
+    v3, r3, it3, _ = sess.result(100)
+    d3 = sess.status()[2]
+    assert (it1, it3) == (1, 3) and d3 < d1 * 0.85
+    assert abs(float(r3.double().sum()) - 1.0) < 1e-4 and float(r3.min()) > 0.0
+    # iteration 1 of a sample of rows, from the CSC: pr1[v] = (alpha * d0 + 1 - alpha) / V + alpha * sum x0[u]
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    hubs = torch.topk(indeg, 8).indices.cpu()
+    sample = torch.cat([hubs, torch.randint(0, nv, (2000,), generator=gen)]).cuda()
+    d0 = float((outdeg == 0).sum()) / nv
+    base = (0.85 * d0 + 0.15) / nv
+    x0 = (1.0 / nv) / torch.clamp(outdeg, min=1).double()
+    want1 = torch.empty(sample.numel(), dtype=torch.float64, device="cuda")
+    for i, vtx in enumerate(sample.tolist()):
+        want1[i] = base + 0.85 * float(x0[idx[int(off[vtx]):int(off[vtx + 1])].long()].sum())
+    got1 = r1[sample].double()
+    assert float(((got1 - want1).abs() / want1).max()) <= 1e-5
 
 
 def test_two_regions_of_the_gathered_vector(monkeypatch):

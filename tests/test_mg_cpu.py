@@ -32,7 +32,7 @@ def _worker(rank, world, port, case, out_dir):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["CUGRAPH_AMD_MG_REGIONS"] = case.get("regions", "auto")  # two regions of the gathered vector
+    os.environ["CUGRAPH_AMD_MG_REGIONS"] = case.get("regions", "0")  # two regions of the gathered vector
     # rows of in-degree 1-3 in the order of their smallest source slot (default: big graphs only)
     os.environ["CUGRAPH_AMD_RENUMBER_LOCALITY"] = case.get("locality", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -110,12 +110,15 @@ def _rmat_case(scale, weighted, **extra):
 
 
 @pytest.mark.parametrize("world,regions,want_regions", [(2, "auto", False), (2, "1", True), (3, "1", True),
-                                                        (4, "auto", True), (4, "0", False)])
+                                                        (4, "auto", True), (4, "0", False), (4, None, False)])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_mg_matches_single_process_oracle(world, regions, want_regions, weighted, tmp_path):
     """regions: the gathered vector as two regions (hot slots first), two all-gathers per iteration and
-    the iteration in two phases -- by default from 4 ranks (the stand-in's window is 48 slots)"""
-    case = _rmat_case(9, weighted, regions=regions, want_regions=want_regions, locality="1" if world >= 3 else "0")
+    the iteration in two phases -- opt-in ("1", or "auto" = from 4 ranks; the stand-in's window is 48
+    slots); off when nothing is said (None)"""
+    case = _rmat_case(9, weighted, want_regions=want_regions, locality="1" if world >= 3 else "0")
+    if regions is not None:
+        case["regions"] = regions
     fulls, metas = _run(world, case, tmp_path)
     o_pr, o_it, o_conv = _oracle(case)
     for f, m in zip(fulls, metas):
