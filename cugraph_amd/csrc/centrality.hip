@@ -232,9 +232,9 @@ CentralityResult* katz_impl(Handle const& h, Graph& g, ArrayView const* betas, d
                             bool do_expensive_check)
 {
   (void)do_expensive_check;  // no initial guess through the C API (katz.cpp:131: has_initial_guess = false)
-  CGA_EXPECTS(alpha_d >= 0.0 && alpha_d <= 1.0, CUGRAPH_INVALID_INPUT,
+  CGA_EXPECTS(alpha_d >= 0.0 && alpha_d <= 1.0, kAlgorithmRejects,
               "Invalid input argument: alpha should be in [0.0, 1.0].");
-  CGA_EXPECTS(epsilon_d >= 0.0, CUGRAPH_INVALID_INPUT,
+  CGA_EXPECTS(epsilon_d >= 0.0, kAlgorithmRejects,
               "Invalid input argument: epsilon should be non-negative.");
   T alpha = static_cast<T>(alpha_d), beta = static_cast<T>(beta_d), epsilon = static_cast<T>(epsilon_d);
   int64_t n = g.num_vertices;
@@ -291,7 +291,7 @@ CentralityResult* eigenvector_impl(Handle const& h, Graph& g, double epsilon_d, 
                                    bool do_expensive_check)
 {
   (void)do_expensive_check;
-  CGA_EXPECTS(epsilon_d >= 0.0, CUGRAPH_INVALID_INPUT,
+  CGA_EXPECTS(epsilon_d >= 0.0, kAlgorithmRejects,
               "Invalid input argument: epsilon should be non-negative.");
   T epsilon = static_cast<T>(epsilon_d);
   int64_t n = g.num_vertices;
@@ -355,7 +355,7 @@ HitsResult* hits_impl(Handle const& h, Graph& g, double epsilon_d, size_t max_it
                       ArrayView const* guess_v, ArrayView const* guess_x, bool normalize,
                       bool do_expensive_check)
 {
-  CGA_EXPECTS(epsilon_d >= 0.0, CUGRAPH_INVALID_INPUT,
+  CGA_EXPECTS(epsilon_d >= 0.0, kAlgorithmRejects,
               "Invalid input argument: epsilon should be non-negative.");
   int64_t n = g.num_vertices;
   auto res  = std::make_unique<HitsResult>();
@@ -413,7 +413,7 @@ HitsResult* hits_impl(Handle const& h, Graph& g, double epsilon_d, size_t max_it
       CGA_HIP(hipMemsetAsync(hubs.p, 0, vb, h.stream));
       dense_from_pairs<T>(h, g, *guess_v, *guess_x, hubs.as<T>(), "initial_hubs_guess");
       if (do_expensive_check)
-        CGA_EXPECTS(ops.reduce(Red::kNegCount, hubs.as<T>()) == 0.0, CUGRAPH_INVALID_INPUT,
+        CGA_EXPECTS(ops.reduce(Red::kNegCount, hubs.as<T>()) == 0.0, kAlgorithmRejects,
                     "Invalid input argument: initial guess values should be non-negative.");
       double s = ops.reduce(Red::kSum, hubs.as<T>());
       CGA_EXPECTS(s > 0.0, CUGRAPH_UNKNOWN_ERROR, "Norm is required to be a positive value.");

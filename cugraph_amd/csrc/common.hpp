@@ -37,6 +37,13 @@ struct Failure : std::runtime_error {
     }                                                                                          \
   } while (0)
 
+// An argument the ALGORITHM rejects (alpha outside [0, 1], a negative epsilon, personalization
+// values that sum to zero, ...): the reference throws these out of cugraph::pagerank & co., and
+// run_algorithm turns every such exception into CUGRAPH_UNKNOWN_ERROR (cpp/src/c_api/utils.hpp:53-55;
+// pylibcugraph then raises RuntimeError).  CUGRAPH_INVALID_INPUT stays what the C layer's own
+// CAPI_EXPECTS checks return (type and size mismatches, pagerank.cpp:268-299).
+constexpr cugraph_error_code_t kAlgorithmRejects = CUGRAPH_UNKNOWN_ERROR;
+
 #define CGA_EXPECTS(cond, code, msg)                 \
   do {                                               \
     if (!(cond)) throw cga::Failure((code), (msg)); \

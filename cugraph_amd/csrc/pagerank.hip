@@ -1349,6 +1349,18 @@ __global__ void scatter_pairs_kernel(IdT const* __restrict__ ids, ValT const* __
   }
 }
 
+// do_expensive_check: personalization vertices must not repeat (pagerank_impl.cuh:170-187)
+template <typename IdT>
+__global__ void count_repeated_ids_kernel(IdT const* __restrict__ ids, int64_t n, IdMap map,
+                                          unsigned int* __restrict__ seen, unsigned int* __restrict__ n_repeated)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = map.row(static_cast<int64_t>(ids[i]));
+    if (v >= 0 && atomicAdd(&seen[v], 1u) > 0u) atomicAdd(n_repeated, 1u);
+  }
+}
+
 template <typename ValT>
 __global__ void permute_out_kernel(ValT const* __restrict__ in, int32_t const* __restrict__ order,
                                    int64_t n, ValT* __restrict__ out)
@@ -2187,6 +2199,19 @@ void session_setup(Session& s, PagerankArgs const& a)
   CGA_HIP(hipMemsetAsync(s.x[0].p, 0, s.x[0].bytes, stream));
   CGA_HIP(hipMemsetAsync(s.x[1].p, 0, s.x[1].bytes, stream));
 
+  // ---- do_expensive_check: no negative edge weight (pagerank_impl.cuh:119-131)
+  if (a.do_expensive_check && g.weights && g.num_edges > 0) {
+    DevBuf chk(sizeof(double) + sizeof(unsigned int) * 2);
+    CGA_HIP(hipMemsetAsync(chk.p, 0, chk.bytes, stream));
+    hipLaunchKernelGGL((value_checks_kernel<ValT>), dim3(grid_for(g.num_edges, 4096)), dim3(kThreads), 0, stream,
+                       static_cast<ValT const*>(g.weights), g.num_edges, chk.as<double>(),
+                       reinterpret_cast<unsigned int*>(chk.as<double>() + 1));
+    unsigned int neg = 0;
+    CGA_HIP(hipMemcpyAsync(&neg, chk.as<double>() + 1, sizeof(neg), hipMemcpyDeviceToHost, stream));
+    CGA_HIP(hipStreamSynchronize(stream));
+    CGA_EXPECTS(neg == 0, kAlgorithmRejects,
+                "Invalid input argument: input edge weights should have non-negative values.");
+  }
   // ---- out-weight sums: given (pagerank.cpp:158-184) or computed once per graph and cached
   if (a.pre_sums) {
     CGA_HIP(hipMemsetAsync(s.out_w.p, 0, s.out_w.bytes, stream));
@@ -2201,7 +2226,7 @@ void session_setup(Session& s, PagerankArgs const& a)
       unsigned int neg = 0;
       CGA_HIP(hipMemcpyAsync(&neg, chk.as<double>() + 1, sizeof(neg), hipMemcpyDeviceToHost, stream));
       CGA_HIP(hipStreamSynchronize(stream));
-      CGA_EXPECTS(neg == 0, CUGRAPH_INVALID_INPUT,
+      CGA_EXPECTS(neg == 0, kAlgorithmRejects,
                   "Invalid input argument: outgoing edge weight sum values should be non-negative.");
     }
   } else {
@@ -2232,14 +2257,14 @@ void session_setup(Session& s, PagerankArgs const& a)
   // ---- personalization (pagerank.cpp:127-156; pagerank_impl.cuh:213-226, 299-319)
   s.personalized = a.pers_vertices != nullptr;
   if (s.personalized) {
-    CGA_EXPECTS(a.pers_values && a.pers_vertices->size == a.pers_values->size, CUGRAPH_INVALID_INPUT,
+    CGA_EXPECTS(a.pers_values && a.pers_vertices->size == a.pers_values->size, kAlgorithmRejects,
                 "Invalid input argument: if personalization.has_value() is true, the size of "
                 "vertices and values should match");
     int64_t np = static_cast<int64_t>(a.pers_vertices->size);
     // in a 1D partition a rank may hold no personalization vertex; the sum is supplied
     // pre-normalised by the driver in that case (values already divided by the global sum)
     bool local_only = g.num_global_vertices != g.num_vertices;
-    CGA_EXPECTS(local_only || np > 0, CUGRAPH_INVALID_INPUT,
+    CGA_EXPECTS(local_only || np > 0, kAlgorithmRejects,
                 "Invalid input argument: if personalizations.has_value() is true, the input "
                 "personalization vector size should not be 0.");
     s.pers_dense.alloc(static_cast<size_t>(nl > 0 ? nl : 1) * vb);
@@ -2260,13 +2285,30 @@ void session_setup(Session& s, PagerankArgs const& a)
     } h_chk{};
     CGA_HIP(hipMemcpyAsync(&h_chk, chk.p, sizeof(h_chk), hipMemcpyDeviceToHost, stream));
     CGA_HIP(hipStreamSynchronize(stream));
-    if (a.do_expensive_check)
-      CGA_EXPECTS(h_chk.neg == 0, CUGRAPH_INVALID_INPUT,
+    if (a.do_expensive_check) {
+      CGA_EXPECTS(h_chk.neg == 0, kAlgorithmRejects,
                   "Invalid input argument: peresonalization values should be non-negative.");
+      if (np > 1 && nl > 0) {
+        DevBuf seen(static_cast<size_t>(nl + 1) * sizeof(unsigned int));
+        CGA_HIP(hipMemsetAsync(seen.p, 0, seen.bytes, stream));
+        unsigned int* n_rep = seen.as<unsigned int>() + nl;
+        if (a.pers_vertices->type == INT32)
+          hipLaunchKernelGGL((count_repeated_ids_kernel<int32_t>), dim3(grid_for(np)), dim3(kThreads), 0, stream,
+                             static_cast<int32_t const*>(a.pers_vertices->data), np, idmap, seen.as<unsigned int>(), n_rep);
+        else
+          hipLaunchKernelGGL((count_repeated_ids_kernel<int64_t>), dim3(grid_for(np)), dim3(kThreads), 0, stream,
+                             static_cast<int64_t const*>(a.pers_vertices->data), np, idmap, seen.as<unsigned int>(), n_rep);
+        unsigned int h_rep = 0;
+        CGA_HIP(hipMemcpyAsync(&h_rep, n_rep, sizeof(h_rep), hipMemcpyDeviceToHost, stream));
+        CGA_HIP(hipStreamSynchronize(stream));
+        CGA_EXPECTS(h_rep == 0, kAlgorithmRejects,
+                    "Invalid input argument: personalization vertices not contain duplicate entries.");
+      }
+    }
     if (!local_only) {
       // the reference keeps the sum in result_t
       double psum = static_cast<double>(static_cast<ValT>(h_chk.sum));
-      CGA_EXPECTS(psum > 0.0, CUGRAPH_INVALID_INPUT,
+      CGA_EXPECTS(psum > 0.0, kAlgorithmRejects,
                   "Invalid input argument: sum of personalization valuese should be positive.");
       if (nl > 0)
         hipLaunchKernelGGL((scale_kernel<ValT>), dim3(grid_for(nl)), dim3(kThreads), 0, stream,
@@ -2486,9 +2528,9 @@ void enqueue_dispatch(Session& s, hipEvent_t b, hipEvent_t e, int phase = -1)
 
 Session* session_create(Handle const& h, Graph& g, PagerankArgs const& a)
 {
-  CGA_EXPECTS(a.alpha >= 0.0 && a.alpha <= 1.0, CUGRAPH_INVALID_INPUT,
+  CGA_EXPECTS(a.alpha >= 0.0 && a.alpha <= 1.0, kAlgorithmRejects,
               "Invalid input argument: alpha should be in [0.0, 1.0].");
-  CGA_EXPECTS(a.epsilon >= 0.0, CUGRAPH_INVALID_INPUT,
+  CGA_EXPECTS(a.epsilon >= 0.0, kAlgorithmRejects,
               "Invalid input argument: epsilon should be non-negative.");
   if (!g.store_transposed) transpose_graph(h, g);  // pagerank.cpp:105-110: mutates the graph
   auto s      = new Session();

@@ -11,40 +11,38 @@ from .exceptions import FailedToConvergeError
 from .graph import Graph
 
 
-def ensure_valid_dtype(input_graph, input_df, input_df_name):
-    """pagerank.py:45-80, same warning texts"""
-    if input_graph.edgelist.weights is False:
-        # an unweighted graph computes in float32 (graph_sg.cpp:247)
-        edge_attr_dtype = np.dtype(np.float32)
-    else:
-        edge_attr_dtype = input_graph.edgelist.edgelist_df["weights"].dtype
-    if "values" in input_df.columns:
-        input_df_values_dtype = input_df["values"].dtype
-        if input_df_values_dtype != edge_attr_dtype:
-            warning_msg = (
-                f"PageRank requires '{input_df_name}' values "
-                "to match the graph's 'edge_attr' type. "
-                f"edge_attr type is: {edge_attr_dtype} and got "
-                f"'{input_df_name}' values of type: "
-                f"{input_df_values_dtype}."
-            )
-            warnings.warn(warning_msg, UserWarning)
-            input_df = input_df.astype({"values": edge_attr_dtype})
-    if input_graph.renumber_map is not None:
-        return input_df  # vertices are translated through the number map (_vertex_ids)
-    vertex_dtype = input_graph.edgelist.edgelist_df.dtypes.iloc[0]
-    input_df_vertex_dtype = input_df["vertex"].dtype
-    if input_df_vertex_dtype != vertex_dtype:
-        warning_msg = (
-            f"PageRank requires '{input_df_name}' vertex "
-            "to match the graph's 'vertex' type. "
-            f"input graph's vertex type is: {vertex_dtype} and got "
-            f"'{input_df_name}' vertex of type: "
-            f"{input_df_vertex_dtype}."
-        )
-        warnings.warn(warning_msg, UserWarning)
-        input_df = input_df.astype({"vertex": vertex_dtype})
-    return input_df
+# The two warning texts are contract: the reference's tests assert them word for word
+# (python/cugraph/cugraph/tests/link_analysis/test_pagerank.py:391-410).  {0}: frame name, {1}: the
+# graph's dtype, {2}: the frame's.
+_DTYPE_WARNINGS = {
+    "values": ("PageRank requires '{0}' values to match the graph's 'edge_attr' type. "
+               "edge_attr type is: {1} and got '{0}' values of type: {2}."),
+    "vertex": ("PageRank requires '{0}' vertex to match the graph's 'vertex' type. "
+               "input graph's vertex type is: {1} and got '{0}' vertex of type: {2}."),
+}
+
+
+def _graph_value_dtype(G):
+    """The type PageRank computes in: the weights' type, float32 for an unweighted graph (graph_sg.cpp:247)."""
+    if G.edgelist.weights is False:
+        return np.dtype(np.float32)
+    return G.edgelist.edgelist_df["weights"].dtype
+
+
+def _match_graph_dtypes(G, frame, name):
+    """A (vertex, values) frame with its columns cast to what the C layer insists on -- value
+    arrays of the graph's weight type, vertex arrays of its vertex type (pagerank.cpp:268-299) --
+    warning once per column that had to be cast (the behaviour of pagerank.py:45-80).  Vertices of
+    a graph with a host-side number map are translated later (_vertex_ids): nothing to match."""
+    wanted = {"values": _graph_value_dtype(G)}
+    if G.renumber_map is None:
+        wanted["vertex"] = G.edgelist.edgelist_df.dtypes.iloc[0]
+    casts = {}
+    for column, dtype in wanted.items():
+        if column in frame.columns and frame[column].dtype != dtype:
+            warnings.warn(_DTYPE_WARNINGS[column].format(name, dtype, frame[column].dtype), UserWarning)
+            casts[column] = dtype
+    return frame.astype(casts) if casts else frame
 
 
 def _graph_from_nx(nxG, weight, store_transposed):
@@ -122,15 +120,12 @@ def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=
     # the library takes external ids directly (number_map lives below the C ABI), so the
     # reference's renumber_vertices / unrenumber round trips (pagerank.py:33-40, 299-300) vanish
     if nstart is not None:
-        nstart = ensure_valid_dtype(G, nstart, "nstart")
+        nstart = _match_graph_dtypes(G, nstart, "nstart")
         initial_guess_vertices, initial_guess_values = _vertex_ids(G, nstart), _dev(nstart["values"])
     if precomputed_vertex_out_weight is not None:
-        precomputed_vertex_out_weight = ensure_valid_dtype(G, precomputed_vertex_out_weight,
-                                                           "precomputed_vertex_out_weight")
-        sums = precomputed_vertex_out_weight["sums"]
-        want = np.float32 if G.edgelist.weights is False else G.edgelist.edgelist_df["weights"].dtype
-        if sums.dtype != want:
-            sums = sums.astype(want)
+        precomputed_vertex_out_weight = _match_graph_dtypes(G, precomputed_vertex_out_weight,
+                                                            "precomputed_vertex_out_weight")
+        sums = precomputed_vertex_out_weight["sums"].astype(_graph_value_dtype(G), copy=False)
         pre_vtx_o_wgt_vertices = _vertex_ids(G, precomputed_vertex_out_weight)
         pre_vtx_o_wgt_sums = _dev(sums)
     try:
@@ -140,7 +135,7 @@ def pagerank(G, alpha=0.85, personalization=None, precomputed_vertex_out_weight=
                     "personalization other than a cudf dataframe currently not "
                     "supported"
                 )
-            personalization = ensure_valid_dtype(G, personalization, "personalization")
+            personalization = _match_graph_dtypes(G, personalization, "personalization")
             result_tuple = plc.personalized_pagerank(
                 resource_handle=G._resource_handle,
                 graph=G._plc_graph,

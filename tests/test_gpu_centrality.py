@@ -78,8 +78,15 @@ def test_non_convergence_is_an_error():
         plc.eigenvector_centrality(h, g, 1e-12, 1, False)
     with pytest.raises(RuntimeError, match="HITS failed to converge"):
         plc.hits(h, g, 1e-12, 1, None, None, True, False)
-    with pytest.raises(ValueError):
+    # arguments the algorithm rejects come back as CUGRAPH_UNKNOWN_ERROR too (utils.hpp:53-55)
+    with pytest.raises(RuntimeError, match=r"alpha should be in \[0.0, 1.0\]"):
         plc.katz_centrality(h, g, None, 1.5, 1.0, 1e-6, 100, False)
+    with pytest.raises(RuntimeError, match="epsilon should be non-negative"):
+        plc.katz_centrality(h, g, None, 0.01, 1.0, -1e-6, 100, False)
+    with pytest.raises(RuntimeError, match="epsilon should be non-negative"):
+        plc.eigenvector_centrality(h, g, -1.0, 10, False)
+    with pytest.raises(RuntimeError, match="epsilon should be non-negative"):
+        plc.hits(h, g, -1.0, 10, None, None, True, False)
 
 
 @pytest.mark.parametrize("scale", [12, 16])

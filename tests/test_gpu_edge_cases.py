@@ -201,3 +201,55 @@ def test_expensive_check_csr_input():
         _build(off, idx, input_type="CSR", transposed=False)
     _build(off, idx, input_type="CSR", transposed=False, multigraph=True)
     _build(off, idx, input_type="CSR", transposed=False, check=False)
+
+
+def test_arguments_the_algorithm_rejects_are_unknown_errors_with_the_reference_messages():
+    """cugraph::pagerank throws on these and run_algorithm maps every exception to CUGRAPH_UNKNOWN_ERROR
+    (cpp/src/c_api/utils.hpp:53-55), which pylibcugraph raises as RuntimeError (utils.pyx:37-83); the texts are
+    pagerank_impl.cuh:89-99, 223-225.  CUGRAPH_INVALID_INPUT (ValueError) stays for the C layer's own type
+    checks (pagerank.cpp:268-299)."""
+    from cugraph_amd import pylibcugraph as plc
+
+    g, h = make_sg_graph(np.array([0, 1, 2], np.int32), np.array([1, 2, 0], np.int32), np.ones(3, np.float32),
+                         vertices=np.arange(3, dtype=np.int32))
+    with pytest.raises(RuntimeError, match=r"alpha should be in \[0.0, 1.0\]"):
+        plc.pagerank(h, g, None, None, None, None, 1.5, 1e-6, 100, False)
+    with pytest.raises(RuntimeError, match="epsilon should be non-negative"):
+        plc.pagerank(h, g, None, None, None, None, 0.85, -1e-6, 100, False)
+    pv = to_dev(np.array([0, 1], np.int32))
+    with pytest.raises(RuntimeError, match="sum of personalization valuese should be positive"):
+        plc.personalized_pagerank(h, g, None, None, None, None, pv, to_dev(np.zeros(2, np.float32)), 0.85, 1e-6,
+                                  100, False)
+    with pytest.raises(RuntimeError, match="personalization vector size should not be 0"):
+        plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.zeros(0, np.int32)),
+                                  to_dev(np.zeros(0, np.float32)), 0.85, 1e-6, 100, False)
+    with pytest.raises(ValueError):  # a value array of the wrong type: the C layer's check
+        plc.personalized_pagerank(h, g, None, None, None, None, pv, to_dev(np.ones(2, np.float64)), 0.85, 1e-6,
+                                  100, False)
+
+
+def test_do_expensive_check_of_the_pagerank_call():
+    """pagerank_impl.cuh:101-187: negative edge weights, negative out-weight sums, negative or repeated
+    personalization entries -- only looked for under do_expensive_check."""
+    from cugraph_amd import pylibcugraph as plc
+
+    src, dst = np.array([0, 1, 2, 2], np.int32), np.array([1, 2, 0, 1], np.int32)
+    g_neg, h = make_sg_graph(src, dst, np.array([1, -2, 1, 1], np.float32), vertices=np.arange(3, dtype=np.int32))
+    with pytest.raises(RuntimeError, match="input edge weights should have non-negative values"):
+        plc.pagerank(h, g_neg, None, None, None, None, 0.85, 1e-6, 100, True)
+    plc.pagerank(h, g_neg, None, None, None, None, 0.85, 1e-6, 5, False, fail_on_nonconvergence=False)  # unchecked
+    g, h = make_sg_graph(src, dst, np.ones(4, np.float32), vertices=np.arange(3, dtype=np.int32), handle=h)
+    ids = to_dev(np.arange(3, dtype=np.int32))
+    with pytest.raises(RuntimeError, match="outgoing edge weight sum values should be non-negative"):
+        plc.pagerank(h, g, ids, to_dev(np.array([1, -1, 2], np.float32)), None, None, 0.85, 1e-6, 100, True)
+    rep_v, rep_x = to_dev(np.array([0, 2, 0], np.int32)), to_dev(np.array([0.2, 0.3, 0.5], np.float32))
+    with pytest.raises(RuntimeError, match="personalization vertices not contain duplicate entries"):
+        plc.personalized_pagerank(h, g, None, None, None, None, rep_v, rep_x, 0.85, 1e-6, 100, True)
+    # unchecked, repeated entries add up (the accumulate scatter): the same as {0: 0.7, 2: 0.3}
+    _, a = plc.personalized_pagerank(h, g, None, None, None, None, rep_v, rep_x, 0.85, 1e-7, 200, False)
+    _, b = plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.array([0, 2], np.int32)),
+                                     to_dev(np.array([0.7, 0.3], np.float32)), 0.85, 1e-7, 200, False)
+    assert np.max(np.abs(a.cpu().numpy() - b.cpu().numpy())) < 1e-6
+    with pytest.raises(RuntimeError, match="peresonalization values should be non-negative"):
+        plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.array([0, 1], np.int32)),
+                                  to_dev(np.array([1.0, -0.25], np.float32)), 0.85, 1e-6, 100, True)
