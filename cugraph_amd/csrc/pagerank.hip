@@ -2175,8 +2175,10 @@ void session_setup(Session& s, PagerankArgs const& a)
 
   // 1D partition: rank r owns destinations [r*chunk, min((r+1)*chunk, V)), chunk = ceil(V / P);
   // the gathered vector is padded to P equal chunks so that one all-gather fills it
+  // (with a compact source space the destination ranges may be ANY contiguous cover of the
+  // vertices -- the driver balances them by in-edges --: the slots define the gathered vector)
   s.x_len = ng;
-  if (g.num_global_vertices != g.num_vertices || s.handle->comm_size > 1) {
+  if (!g.x_pos && (g.num_global_vertices != g.num_vertices || s.handle->comm_size > 1)) {
     int64_t P     = s.handle->comm_size;
     int64_t chunk = (ng + P - 1) / P;
     int64_t first = std::min<int64_t>(chunk * s.handle->rank, ng);

@@ -20,7 +20,12 @@ SURVEY.md section 2.3:
                host_scalar_allreduce, reduce_v.cuh:141-144);
   stop       : decided on the device from the all-reduced delta, identically on every rank.
 
-Rank r owns destinations [r*chunk, min((r+1)*chunk, V)) with chunk = ceil(V / P).
+Rank r owns the destinations [bounds[r], bounds[r+1]): contiguous ranges cut so that every rank
+receives about E / P in-edges (`edge_balanced_bounds`: bisection on the global in-degree prefix, one
+all-reduced coarse histogram plus an exact one inside the P-1 buckets that hold a cut; SURVEY 8e --
+the reference balances through its 2D grid, partition_manager.hpp:32-145).  Ownership of a vertex is
+a search of the P+1 bounds.  CUGRAPH_AMD_MG_PARTITION=equal keeps equal vertex ranges
+(chunk = ceil(V / P)), which is also the fallback for a graph without edges.
 
 Inside its range every rank relabels its vertices by descending in-degree (the reference renumbers
 by degree inside each partition too, renumber_edgelist_impl.cuh); the ranks all-gather the
@@ -50,6 +55,72 @@ def partition_bounds(num_vertices, world_size, rank):
     first = min(rank * chunk, num_vertices)
     last = min(first + chunk, num_vertices)
     return first, last, chunk
+
+
+def equal_bounds(num_vertices, world_size):
+    """[0, chunk, 2*chunk, ..., V] clipped to V: P+1 bounds of equal vertex ranges."""
+    chunk = (num_vertices + world_size - 1) // world_size
+    return [min(r * chunk, num_vertices) for r in range(world_size + 1)]
+
+
+def edge_balanced_bounds(dst, num_vertices, world, group=None, coarse_buckets=1 << 16):
+    """P+1 bounds of contiguous destination ranges that hold about E / P in-edges each.  dst: this
+    rank's share of the destination ids (any share: the histograms are all-reduced).  Two levels:
+    in-edge counts of at most `coarse_buckets` equal runs of vertices find the run every cut falls
+    into; per-vertex counts inside those P-1 runs place it exactly.  The same on every rank."""
+    import torch
+
+    nv = int(num_vertices)
+    if world == 1 or nv == 0:
+        return equal_bounds(nv, world)
+    dist = _dist()
+    width = max(1, -(-nv // coarse_buckets))
+    nb = -(-nv // width)
+    d64 = dst.to(torch.int64)
+    hist = torch.bincount(torch.div(d64, width, rounding_mode="floor"), minlength=nb).to(torch.int64)
+    dist.all_reduce(hist, group=group)
+    prefix = torch.cumsum(hist, 0).cpu().numpy()  # edges of buckets 0..b
+    total = int(prefix[-1]) if nb else 0
+    if total == 0:
+        return equal_bounds(nv, world)
+    targets = [total * r // world for r in range(1, world)]
+    cut_bucket = [int(np.searchsorted(prefix, t, side="left")) for t in targets]  # first bucket reaching t
+    if width == 1:
+        fine = None
+    else:
+        fine = torch.zeros((world - 1, width), dtype=torch.int64, device=dst.device)
+        for i, b in enumerate(cut_bucket):
+            lo = b * width
+            inside = d64[(d64 >= lo) & (d64 < lo + width)] - lo
+            fine[i] = torch.bincount(inside, minlength=width)
+        dist.all_reduce(fine, group=group)
+        fine = fine.cpu().numpy()
+    bounds = [0]
+    for i, (t, b) in enumerate(zip(targets, cut_bucket)):
+        before = int(prefix[b - 1]) if b > 0 else 0
+        counts = np.array([int(prefix[b]) - before]) if fine is None else fine[i]
+        upto = before + np.cumsum(counts)  # edges of the vertices up to and including lo + j
+        j = int(np.searchsorted(upto, t, side="left"))  # first vertex with which the target is reached
+        # cut after that vertex or before it, whichever leaves the smaller error
+        after = int(upto[j]) if j < len(upto) else int(upto[-1])
+        ahead = int(upto[j - 1]) if j > 0 else before
+        cut = b * width + (j + 1 if abs(after - t) <= abs(t - ahead) else j)
+        bounds.append(min(max(cut, bounds[-1]), nv))
+    bounds.append(nv)
+    return bounds
+
+
+def all_gather_ragged(local, lengths, rank, world, group=None, fill=0):
+    """Concatenation of every rank's `local` (rank r's has lengths[r] elements): padded to the
+    longest, one all-gather, the pads dropped."""
+    import torch
+
+    longest = max(max(lengths), 1)
+    buf = torch.full((world * longest,), fill, dtype=local.dtype, device=local.device)
+    buf[rank * longest:rank * longest + lengths[rank]] = local
+    if world > 1:
+        all_gather_in_place(buf, longest, rank, world, group)
+    return torch.cat([buf[r * longest:r * longest + lengths[r]] for r in range(world)])
 
 
 def _dist():
@@ -90,12 +161,14 @@ def all_gather_region_async(region, sub_chunk, rank, world, group=None):
         return _Done()
 
 
-def shuffle_edges_to_owner(src, dst, wgt, chunk, world, group=None):
-    """Route every edge to the rank that owns its destination (one all-to-all per array)."""
+def shuffle_edges_to_owner(src, dst, wgt, bounds, world, group=None):
+    """Route every edge to the rank that owns its destination (one all-to-all per array).
+    bounds: the P+1 bounds of the destination ranges."""
     import torch
 
     dist = _dist()
-    owner = torch.div(dst, chunk, rounding_mode="floor").to(torch.int64)
+    inner = torch.as_tensor(bounds[1:-1], dtype=torch.int64, device=dst.device)
+    owner = torch.bucketize(dst.to(torch.int64), inner, right=True)
     order = torch.argsort(owner, stable=True)
     send_counts = torch.bincount(owner, minlength=world)
     recv_counts = torch.empty_like(send_counts)
@@ -202,7 +275,7 @@ class MGPagerank:
         self.always_exchange = False  # run the collectives even at world size 1 (tests)
         self.num_vertices = int(num_vertices)
         self.rank, self.world, self.group = rank, world, group
-        self.first, self.last, self.chunk = partition_bounds(self.num_vertices, world, rank)
+        self.set_bounds(equal_bounds(self.num_vertices, world))
         self.graph = None
         self.order = None  # int32[n_local]: internal position -> offset of the caller's id in the range
         self.rank_local = None  # int32[n_local]: offset of the caller's id in the range -> internal position
@@ -215,6 +288,11 @@ class MGPagerank:
         self.vertex_dtype = None
         self.t_generate = 0.0
         self.t_build = 0.0
+
+    def set_bounds(self, bounds):
+        self.bounds = [int(b) for b in bounds]
+        self.lengths = [b - a for a, b in zip(self.bounds, self.bounds[1:])]
+        self.first, self.last = self.bounds[self.rank], self.bounds[self.rank + 1]
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -230,8 +308,10 @@ class MGPagerank:
         t0 = time.perf_counter()
         self.vertex_dtype = src.dtype
         self.value_dtype = torch.float32 if wgt is None else wgt.dtype
+        if os.environ.get("CUGRAPH_AMD_MG_PARTITION", "edges") != "equal":
+            self.set_bounds(edge_balanced_bounds(dst, self.num_vertices, world, group))
         if world > 1:
-            src, dst, wgt = shuffle_edges_to_owner(src, dst, wgt, self.chunk, world, group)
+            src, dst, wgt = shuffle_edges_to_owner(src, dst, wgt, self.bounds, world, group)
         # out-edge counts and out-weight sums per source, over all ranks
         counts = engine.source_weight_sums(src, None, self.num_vertices)
         sums = counts if wgt is None else engine.source_weight_sums(src, wgt, self.num_vertices)
@@ -264,10 +344,9 @@ class MGPagerank:
                 slot = torch.where(j < c0, j + rank * c0, j - c0 + world * c0 + rank * c1)
                 n_slots, hot_slots = world * (c0 + c1), world * c0
             x_pos = torch.where(active, slot, torch.full_like(order, -1)).to(torch.int32)
-            slot_of = torch.full((self.chunk * world,), -1, dtype=torch.int32, device=src.device)
-            slot_of[self.first + order] = x_pos
-            if world > 1:
-                all_gather_in_place(slot_of, self.chunk, rank, world, group)
+            mine = torch.full((self.last - self.first,), -1, dtype=torch.int32, device=src.device)
+            mine[order] = x_pos
+            slot_of = all_gather_ragged(mine, self.lengths, rank, world, group, fill=-1)
             return x_pos, slot_of, n_slots, hot_slots
 
         x_pos, slot_of, n_slots, hot_slots = assign_slots()
@@ -571,10 +650,7 @@ class MGPagerank:
         verts, vals, iters, conv = self.result(sess, max_iterations)
         if self.world == 1:
             return vals, iters, conv
-        full = torch.zeros(self.chunk * self.world, dtype=vals.dtype, device=vals.device)
-        full[self.first:self.last] = vals
-        all_gather_in_place(full, self.chunk, self.rank, self.world, self.group)
-        return full[:self.num_vertices], iters, conv
+        return all_gather_ragged(vals, self.lengths, self.rank, self.world, self.group), iters, conv
 
 
 def pagerank(resource_handle, graph_properties, src, dst, wgt, num_vertices, *, alpha=0.85,

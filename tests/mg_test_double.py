@@ -27,8 +27,6 @@ class _Session:
                  pers_v=None, pers_x=None):
         self.g, self.alpha, self.eps = g, alpha, epsilon
         nl = g.last - g.first
-        chunk = (g.num_global + world - 1) // world
-        assert g.first == min(rank * chunk, g.num_global)
         assert g.slots % world == 0 and np.all(g.src < g.slots)
         mine = g.x_pos[g.x_pos >= 0]
         # this rank writes only its own sub-chunk of each region (one region: P equal chunks)

@@ -35,6 +35,7 @@ def _worker(rank, world, port, case, out_dir):
     os.environ["CUGRAPH_AMD_MG_REGIONS"] = case.get("regions", "0")  # two regions of the gathered vector
     # rows of in-degree 1-3 in the order of their smallest source slot (default: big graphs only)
     os.environ["CUGRAPH_AMD_RENUMBER_LOCALITY"] = case.get("locality", "0")
+    os.environ["CUGRAPH_AMD_MG_PARTITION"] = case.get("partition", "edges")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         src, dst, wgt, nv = case["src"], case["dst"], case["wgt"], case["nv"]
@@ -43,8 +44,13 @@ def _worker(rank, world, port, case, out_dir):
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a[sel]))  # noqa: E731
         drv = mg.MGPagerank.from_edges(OracleEngine(rank, world), t(src), t(dst), t(wgt), nv,
                                        rank=rank, world=world)
-        first, last, chunk = mg.partition_bounds(nv, world, rank)
-        assert (drv.first, drv.last) == (first, last)
+        # contiguous ranges that cover the vertices, the same on every rank; equal ones on request
+        assert drv.bounds[0] == 0 and drv.bounds[-1] == nv and len(drv.bounds) == world + 1
+        assert all(a <= b for a, b in zip(drv.bounds, drv.bounds[1:]))
+        first, last = drv.first, drv.last
+        assert (first, last) == (drv.bounds[rank], drv.bounds[rank + 1])
+        if case.get("partition") == "equal":
+            assert (first, last) == mg.partition_bounds(nv, world, rank)[:2]
         if "want_regions" in case:
             assert (drv.regions is not None) == case["want_regions"]
         assert drv.graph.first == first and len(drv.out_w) == last - first
@@ -67,7 +73,8 @@ def _worker(rank, world, port, case, out_dir):
         assert verts.tolist() == list(range(first, last)) and len(vals) == last - first
         np.save(os.path.join(out_dir, f"r{rank}.npy"), full.numpy())
         np.save(os.path.join(out_dir, f"meta{rank}.npy"),
-                np.array([iters, it2, int(stopped), int(conv), delta, dangling], dtype=np.float64))
+                np.array([iters, it2, int(stopped), int(conv), delta, dangling, len(drv.graph.dst), first, last],
+                         dtype=np.float64))
     finally:
         dist.destroy_process_group()
 
@@ -161,6 +168,37 @@ def test_mg_scalars_after_a_stop_inside_a_batch(world, tmp_path):
         assert 0.0 < m[4] < case["eps"]
         assert abs(m[5] - dang) < 1e-9
         assert np.max(np.abs(f - o_pr)) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_edge_balanced_partition_of_unscrambled_rmat(world, tmp_path):
+    """Natural R-MAT ids put the hubs at the low ids: equal vertex ranges would give rank 0 most of
+    the edges (more than twice the mean at 8 ranks).  The driver cuts the ranges by in-edges instead:
+    max / mean of the local edge counts stays within 1.1, and the ranks are still the oracle's."""
+    import oracle
+
+    scale = 12
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = oracle.rmat_edges(scale, ne, seed=7, scramble=False)
+    case = dict(src=src.astype(np.int64), dst=dst.astype(np.int64), wgt=None, nv=nv, eps=nv * 1e-9, max_iter=200,
+                check=4)
+    equal = np.bincount(np.minimum(dst // -(-nv // world), world - 1), minlength=world)
+    assert equal.max() / equal.mean() > 1.5  # what equal ranges would do to this graph
+    fulls, metas = _run(world, case, tmp_path)
+    local_edges = np.array([m[6] for m in metas])
+    assert local_edges.sum() == ne
+    assert local_edges.max() / local_edges.mean() <= 1.1
+    assert [int(m[7]) for m in metas][1:] == [int(m[8]) for m in metas][:-1]  # the ranges tile the vertices
+    o_pr, o_it, _ = _oracle(case)
+    for f, m in zip(fulls, metas):
+        assert m[0] == o_it and np.max(np.abs(f - o_pr)) < 1e-7  # (fp32 at the API for an unweighted graph)
+
+
+def test_equal_ranges_on_request(tmp_path):
+    case = _rmat_case(9, False, partition="equal")
+    fulls, metas = _run(3, case, tmp_path)
+    o_pr, o_it, _ = _oracle(case)
+    assert all(m[0] == o_it and np.max(np.abs(f - o_pr)) < 1e-12 for f, m in zip(fulls, metas))
 
 
 def test_partition_bounds_cover_everything():
