@@ -606,26 +606,15 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
   for (int rot = 0; rot < kXsSlices; ++rot) {
     int const k = (my + rot) & (kXsSlices - 1);
     uint32_t const kbits = static_cast<uint32_t>(k) << shift;
-    // The first wave keeps the queue three items ahead of the item being worked on, so that no
-    // round trip of the queue is ever waited for, however short the items are: in LDS the records
-    // of the current item and the next, in registers the record after those (requested one
-    // boundary ago) and the queue position of the one after that (popped one boundary ago).
-    // The first items of a queue are fetched on the spot.
-    int q_popped      = 0;
-    int64_t r_loading = -1;
+    // the first item of a queue is fetched on the spot, every later one during the item before it
+    // (not further ahead: an item reserved by a busy workgroup is an item an idle one cannot take,
+    // and a small graph has only a few items per workgroup)
     if (wave0) {
-      int q[4] = {0, 0, 0, 0};
-      if (lane == 0) {
-        int const q0 = atomicAdd(&xs.counters[k], 4);
-        q[0] = q0; q[1] = q0 + 1; q[2] = q0 + 2; q[3] = q0 + 3;
-      }
-      int64_t const r0 = load_record(k, __shfl(q[0], 0)), r1 = load_record(k, __shfl(q[1], 0));
-      r_loading = load_record(k, __shfl(q[2], 0));
-      q_popped  = q[3];
-      if (lane < kXsRecWords) {
-        s_rec[buf][lane]     = r0;
-        s_rec[buf ^ 1][lane] = r1;
-      }
+      int q = 0;
+      if (lane == 0) q = atomicAdd(&xs.counters[k], 1);
+      q         = __shfl(q, 0);
+      int64_t r = load_record(k, q);
+      if (lane < kXsRecWords) s_rec[buf][lane] = r;
     }
     __syncthreads();
     while (true) {
@@ -759,6 +748,12 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
           }
         }
       };
+      // the next item is asked for at the start of this one and its record during the first pass,
+      // so neither round trip is waited for; it is parked in LDS at the end
+      int q_next     = 0;
+      int64_t r_next = -1;
+      bool rec_asked = false;
+      if (wave0 && lane == 0) q_next = atomicAdd(&xs.counters[k], 1);
       uint32_t i0 = claim(), i1 = claim();
       if (i0 < n_wp) fetch(pb_lo + i0 * kWavePass, en, w);
       while (i0 < n_wp) {
@@ -782,9 +777,14 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
           pass(std::false_type{}, pb, pb_next, have_next, w_cur, w_hi);
           w_cur = w_hi;
         }
+        if (wave0 && !rec_asked) {
+          r_next    = load_record(k, __shfl(q_next, 0));
+          rec_asked = true;
+        }
         i0 = i1;
         i1 = i2;
       }
+      if (wave0 && !rec_asked) r_next = load_record(k, __shfl(q_next, 0));
       CGA_XSP(pt_a = wall_clock64());
       if (few) {
 #pragma unroll
@@ -808,12 +808,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
         *reinterpret_cast<v2f64_t*>(acc + i + 2) = z;
       }
       CGA_XSP(pt_wbk += wall_clock64() - pt_c);
-      if (wave0) {
-        // the slot of the item that just ended takes the record two items on; the queue moves up
-        if (lane < kXsRecWords) s_rec[buf][lane] = r_loading;
-        r_loading = load_record(k, __shfl(q_popped, 0));
-        if (lane == 0) q_popped = atomicAdd(&xs.counters[k], 1);
-      }
+      if (wave0 && lane < kXsRecWords) s_rec[buf ^ 1][lane] = r_next;
       if (tid == 0) s_claim = 0;
       buf ^= 1;
       lds_barrier();
