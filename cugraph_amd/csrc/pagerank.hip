@@ -1462,6 +1462,11 @@ struct PullPlan {
   // of the compute graph (same offsets and weights, NOT owned) whose indices are slots and whose
   // x_pos maps a row to its slot.  nullptr: every source is addressed by its vertex id.
   Graph* compact{nullptr};
+  // Once the XS tiles exist, the only rows that still read compact->indices are the rows below
+  // the tiles (in-degree < kXsMinDegree: the tail of a degree-sorted graph, 2 % of the edges at
+  // scale 26).  The slot-numbered copy is then cut down to that tail: compact->indices points
+  // tail_first edges BEFORE this buffer, so that the kernels keep indexing it with CSC offsets.
+  DevBuf compact_tail;
   int64_t n_dead{0};  // rows at the very end without in-edges and without a slot (no edge touches them)
   DevBuf lists[kNumBuckets];
   int64_t counts[kNumBuckets]{};
@@ -1487,6 +1492,7 @@ struct PullPlan {
     if (compact) {  // offsets and weights belong to the graph it views
       compact->offsets = nullptr;
       compact->weights = nullptr;
+      if (compact_tail.p) compact->indices = nullptr;  // a biased pointer into compact_tail
       delete compact;
     }
     delete internal;
@@ -1933,6 +1939,21 @@ PullPlan& get_plan(Handle const& h, Graph& g)
           if (f64) build_xs<int32_t, double>(stream, cg, *p);
           else build_xs<int32_t, float>(stream, cg, *p);
         }
+      }
+      if (p->compact && p->xs_on && p->xs_row_first == 0 && std::getenv("CUGRAPH_AMD_KEEP_SLOT_COPY") == nullptr) {
+        // keep the slot numbers of the edges below the XS rows only (see PullPlan::compact_tail)
+        Graph& c = *p->compact;
+        int64_t const tail_first = p->xs_n_edges;  // XS rows are the first rows: their edges the first edges
+        int64_t const n_tail     = c.num_edges - tail_first;
+        DevBuf tail(static_cast<size_t>(n_tail + 8) * sizeof(int32_t));
+        CGA_HIP(hipMemsetAsync(tail.p, 0, tail.bytes, stream));
+        if (n_tail > 0)
+          CGA_HIP(hipMemcpyAsync(tail.p, c.indices + tail_first, static_cast<size_t>(n_tail) * sizeof(int32_t),
+                                 hipMemcpyDeviceToDevice, stream));
+        CGA_HIP(hipStreamSynchronize(stream));
+        CGA_HIP(hipFree(c.indices));
+        p->compact_tail = std::move(tail);
+        c.indices       = p->compact_tail.as<int32_t>() - tail_first;
       }
     } catch (...) {
       delete p;
