@@ -958,11 +958,12 @@ __global__ __launch_bounds__(kThreads) void xs_finish_kernel(IterArgs<OffT, ValT
 // are set k * tile_sets[tile] + item.pset of the tile's sets.
 struct XsItem {
   int32_t tile, piece, pieces, pset;
+  int32_t win_lo, win_hi;  // the windows of its unit the item covers
 };
 __global__ void xs_records_kernel(XsItem const* __restrict__ items, int n_items,
                                   int32_t const* __restrict__ tile_row,
                                   int64_t const* __restrict__ unit_off,
-                                  int64_t const* __restrict__ pbase, int n_win, int win_lo, int win_hi,
+                                  int64_t const* __restrict__ pbase, int n_win,
                                   int64_t* __restrict__ rec)
 {
   int64_t total = static_cast<int64_t>(kXsSlices) * n_items;
@@ -979,8 +980,8 @@ __global__ void xs_records_kernel(XsItem const* __restrict__ items, int n_items,
     r[0] = t | (piece << 32) | (n_pc << 40);
     r[1] = row0 | (rows << 32);
     r[2] = pbase[t] + (k * sets + it.pset) * rows_pad;
-    r[3] = unit_off[u0 + win_lo];
-    r[4] = unit_off[u0 + win_hi];
+    r[3] = unit_off[u0 + it.win_lo];
+    r[4] = unit_off[u0 + it.win_hi];
     for (int w = 1; w < kXsRecWindows; ++w) r[4 + w] = w < n_win ? unit_off[u0 + w] : INT64_MAX;
   }
 }
@@ -1702,25 +1703,63 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipMemcpyAsync(h_row.data(), plan.xs_tile_row.p, static_cast<size_t>(n_tiles + 1) * 4,
                          hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
+  // Source PARTS (single GPU; big and medium tiles): a unit is cut at window boundaries into
+  // parts of part_windows windows -- about 3 MiB of the gathered vector per XCD slice, what an
+  // XCD's L2 holds beside the streams -- and the queue is ordered part-major: first every such
+  // tile's part 0, then every part 1, ...  All workgroups of an XCD then gather from the same few
+  // MiB at a time, so the colder parts, which one sweep of a unit touches line by line (one L2 miss
+  // per line and unit), stay in L2 across the tiles of the phase.  No barrier: the order of the
+  // queue is all there is to it, and the kernel does not know (an item is a window range of a unit
+  // either way).  The price is one more set of partials and one more item boundary per part, so
+  // only tiles with enough entries per part take it; the low-degree tiles follow as whole units.
+  char const* pw_env = std::getenv("CUGRAPH_AMD_XS_PART_WINDOWS");
+  char const* pm_env = std::getenv("CUGRAPH_AMD_XS_PHASE_MIN");
+  int const part_windows  = pw_env ? std::atoi(pw_env) : 3;
+  int64_t const phase_min = pm_env ? std::atoll(pm_env) : (int64_t(1) << 18);  // entries per unit
+  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows) ? (n_win + part_windows - 1) / part_windows : 1;
   std::vector<XsItem> h_items[2];
+  std::vector<std::vector<XsItem>> part_items(n_parts);  // region 0 of phased tiles, by part
   std::vector<int64_t> h_fin;
   std::vector<int64_t> h_pbase(n_tiles + 1);
   int64_t plen = 0;
+  auto pieces_of = [&](int64_t entries_all_slices) {
+    int64_t const per_unit = entries_all_slices / kXsSlices;
+    return static_cast<int32_t>(std::min<int64_t>(15, std::max<int64_t>(1, (per_unit + piece_entries / 2) / piece_entries)));
+  };
   for (int t = 0; t < n_tiles; ++t) {
-    // entries of the tile in each region, per unit on average
-    int64_t cnt[2] = {0, 0};
-    for (int k = 0; k < kXsSlices; ++k) {
-      int64_t u0 = (static_cast<int64_t>(t) * kXsSlices + k) * n_win;
-      int64_t mid = w0 > 0 ? h_uoff[u0 + w0] : h_uoff[u0 + n_win];
-      cnt[0] += mid - h_uoff[u0];
-      cnt[1] += h_uoff[u0 + n_win] - mid;
-    }
+    // entries of the tile per window, over its eight units
+    auto count = [&](int lo, int hi) {
+      int64_t c = 0;
+      for (int k = 0; k < kXsSlices; ++k) {
+        int64_t const u0 = (static_cast<int64_t>(t) * kXsSlices + k) * n_win;
+        c += h_uoff[u0 + hi] - h_uoff[u0 + lo];
+      }
+      return c;
+    };
     int32_t sets = 0;
-    for (int reg = 0; reg < (w0 > 0 ? 2 : 1); ++reg) {
-      int64_t per_unit = cnt[reg] / kXsSlices;
-      int32_t n_pc = static_cast<int32_t>(
-        std::min<int64_t>(15, std::max<int64_t>(1, (per_unit + piece_entries / 2) / piece_entries)));
-      for (int32_t j = 0; j < n_pc; ++j) h_items[reg].push_back(XsItem{t, j, n_pc, sets + j});
+    if (w0 > 0) {  // two regions of a partitioned graph's source space: item lists of their own
+      for (int reg = 0; reg < 2; ++reg) {
+        int const lo = reg == 0 ? 0 : w0, hi = reg == 0 ? w0 : n_win;
+        int32_t const n_pc = pieces_of(count(lo, hi));
+        for (int32_t j = 0; j < n_pc; ++j) h_items[reg].push_back(XsItem{t, j, n_pc, sets + j, lo, hi});
+        sets += n_pc;
+      }
+    } else if (n_parts > 1 && count(0, n_win) / kXsSlices >= phase_min) {
+      for (int part = 0; part < n_parts; ++part) {
+        int const lo = part * part_windows, hi = std::min(n_win, lo + part_windows);
+        int64_t const c = count(lo, hi);
+        if (c == 0) continue;  // nothing to add, no partials
+        int32_t const n_pc = pieces_of(c);
+        for (int32_t j = 0; j < n_pc; ++j) part_items[part].push_back(XsItem{t, j, n_pc, sets + j, lo, hi});
+        sets += n_pc;
+      }
+      if (sets == 0) {  // (cannot happen: the tile has entries) keep the row sums defined
+        part_items[0].push_back(XsItem{t, 0, 1, 0, 0, n_win});
+        sets = 1;
+      }
+    } else {
+      int32_t const n_pc = pieces_of(count(0, n_win));
+      for (int32_t j = 0; j < n_pc; ++j) h_items[0].push_back(XsItem{t, j, n_pc, sets + j, 0, n_win});
       sets += n_pc;
     }
     int64_t const rows_t = h_row[t + 1] - h_row[t];
@@ -1735,6 +1774,12 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
       h_fin.push_back(rows_pad);
     }
   }
+  {  // the queue: the phased tiles part by part, then the whole units of the other tiles
+    std::vector<XsItem> whole;
+    whole.swap(h_items[0]);
+    for (auto const& pi : part_items) h_items[0].insert(h_items[0].end(), pi.begin(), pi.end());
+    h_items[0].insert(h_items[0].end(), whole.begin(), whole.end());
+  }
   h_pbase[n_tiles] = plen;
   if (n_tiles >= (1 << 24) || h_items[0].size() + h_items[1].size() >= 0x7fffffffu / kXsSlices) return;
   plan.xs_pbase.alloc(static_cast<size_t>(n_tiles + 1) * 8);
@@ -1746,11 +1791,10 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     DevBuf items(static_cast<size_t>(n_items) * sizeof(XsItem));
     plan.xs_rec[reg].alloc(static_cast<size_t>(kXsSlices) * n_items * kXsRecWords * 8);
     CGA_HIP(hipMemcpyAsync(items.p, h_items[reg].data(), items.bytes, hipMemcpyHostToDevice, stream));
-    int const lo = reg == 0 ? 0 : w0, hi = (reg == 0 && w0 > 0) ? w0 : n_win;
     hipLaunchKernelGGL(xs_records_kernel, dim3(grid_for(static_cast<int64_t>(kXsSlices) * n_items)),
                        dim3(kThreads), 0, stream, items.as<XsItem>(), n_items,
                        plan.xs_tile_row.as<int32_t>(), plan.xs_unit_off.as<int64_t>(),
-                       plan.xs_pbase.as<int64_t>(), n_win, lo, hi, plan.xs_rec[reg].as<int64_t>());
+                       plan.xs_pbase.as<int64_t>(), n_win, plan.xs_rec[reg].as<int64_t>());
     CGA_HIP(hipGetLastError());
     CGA_HIP(hipStreamSynchronize(stream));
   }
