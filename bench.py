@@ -297,7 +297,7 @@ def main_test_double(args):
 def pmc_traffic(scale, ef, n_gpus):
     """HBM bytes per xs_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
     None when they do not describe this workload.  bench.py cannot run under the profiler itself."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_xs.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc_xs.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -427,7 +427,7 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": pmc_traffic(scale, ef, world),
-        "traffic_source": "profiles/r1_pmc_xs.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command)",
+        "traffic_source": "profiles/r2_pmc_xs.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile_r2.sh)",
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "kernel_ms_avg": kern_avg_ms,
         "iteration_ms_event_avg": float(iter_ms.mean()),
