@@ -277,6 +277,8 @@ CompressedOut compress_coo(hipStream_t stream,
 CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_minor,
                                 int64_t n_edges, int32_t const* majors, int32_t const* minors,
                                 bool ties_in_input_order = true);
+CompressedOut compress_coo_keys(hipStream_t stream, int64_t n_major, int64_t n_edges, int32_t const* majors,
+                                uint32_t const* keys, int sort_from_bit, int sort_to_bit);
 
 // counts[key] += occurrences (counts zeroed by the caller); hubs_first: small keys are the frequent ones
 void histogram_u32(hipStream_t stream, int32_t const* keys, int64_t n, unsigned int* counts, bool hubs_first);

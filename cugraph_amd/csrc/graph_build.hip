@@ -578,7 +578,8 @@ inline int bit_width_u64(uint64_t v)
 
 template <typename OffT, typename KeyT>
 void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t n_major,
-                   int64_t n_minor, int64_t n_edges, bool ties_in_input_order = true)
+                   int64_t n_minor, int64_t n_edges, bool ties_in_input_order = true, int sort_from_bit = 0,
+                   int sort_to_bit = 64)
 {
   if (n_edges < 2) return;
   hipLaunchKernelGGL((sort_small_kernel<OffT, KeyT, 16>), dim3(grid_for(n_major * 16)), dim3(kThreads),
@@ -612,7 +613,8 @@ void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t 
       for (int s = 0; s < bv; s += 8) passes.shift[passes.n++] = 32 + s;
     } else {
       int bv = bit_width_u64(static_cast<uint64_t>(n_minor > 0 ? n_minor - 1 : 0));
-      for (int s = 0; s < bv; s += 8) passes.shift[passes.n++] = s;
+      // (sort_from_bit: the low bits of a packed key that need no order, compress_coo_keys)
+      for (int s = sort_from_bit; s < bv && s < sort_to_bit; s += 8) passes.shift[passes.n++] = s;
     }
     if (passes.n > 0) {
       tmp.alloc(static_cast<size_t>(n_edges) * sizeof(KeyT));
@@ -631,12 +633,14 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
                             int32_t const* majors, int32_t const* minors, void const* weights,
                             size_t weight_size, bool want_perm = false,
                             unsigned int const* major_counts = nullptr, bool ties_in_input_order = true,
-                            bool hubs_first = false)
+                            bool hubs_first = false, int sort_from_bit = 0, int sort_to_bit = 64,
+                            bool grouped = false)
 {
   CompressedOut out;
   // long columns (512 edges or more on average): LDS-privatised histogram and scatter (hist_lds_kernel)
   bool const no_lds     = std::getenv("CUGRAPH_AMD_BUILD_NO_LDS") != nullptr;
-  bool const few_majors = sizeof(OffT) == 4 && n_edges >= (int64_t{1} << 16) && n_edges / 512 >= n_major && !no_lds;
+  // (grouped: the caller says that neighbouring edges have neighbouring majors, whatever their number)
+  bool const few_majors = sizeof(OffT) == 4 && n_edges >= (int64_t{1} << 16) && (n_edges / 512 >= n_major || grouped) && !no_lds;
   // majors in descending degree order: the first kLdsMajors of them take a large share of the edges
   bool const lds_scatter = few_majors || (sizeof(OffT) == 4 && hubs_first && n_edges >= (int64_t{1} << 16) && !no_lds);
   size_t const lds_bytes = static_cast<size_t>(kLdsMajors) * sizeof(unsigned int);
@@ -738,7 +742,7 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
     } else {
       scatter(out.indices.as<uint32_t>());
       order_columns<OffT, uint32_t>(stream, out.offsets.as<OffT>(), out.indices.as<uint32_t>(),
-                                    n_major, n_minor, n_edges);
+                                    n_major, n_minor, n_edges, true, sort_from_bit, sort_to_bit);
     }
   }
   CGA_HIP(hipGetLastError());
@@ -848,6 +852,21 @@ CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_m
                                   nullptr, ties_in_input_order);
   return compress_impl<int64_t>(stream, n_major, n_minor, n_edges, majors, minors, nullptr, 0, true,
                                 nullptr, ties_in_input_order);
+}
+
+// 32-bit keys grouped by major and, inside a major, ascending in their bits [sort_from_bit,
+// sort_to_bit) (the keys of a major agree above; the order of keys that agree in those bits is left
+// open): `indices` of the result are the keys.  The majors arrive grouped (see compress_impl).
+CompressedOut compress_coo_keys(hipStream_t stream, int64_t n_major, int64_t n_edges, int32_t const* majors,
+                                uint32_t const* keys, int sort_from_bit, int sort_to_bit)
+{
+  int32_t const* as_minors = reinterpret_cast<int32_t const*>(keys);
+  int64_t const key_space  = int64_t{1} << 32;
+  if (n_edges < 0x7fffffffLL)
+    return compress_impl<int32_t>(stream, n_major, key_space, n_edges, majors, as_minors, nullptr, 0, false,
+                                  nullptr, true, false, sort_from_bit, sort_to_bit, true);
+  return compress_impl<int64_t>(stream, n_major, key_space, n_edges, majors, as_minors, nullptr, 0, false,
+                                nullptr, true, false, sort_from_bit, sort_to_bit, true);
 }
 
 void expand_offsets(hipStream_t stream, void const* offsets, bool off64, int64_t n_major,

@@ -986,28 +986,68 @@ __global__ void xs_records_kernel(XsItem const* __restrict__ items, int n_items,
   }
 }
 
-// ---- XS build: unit id (tile * 8 + slice) and row of every edge of the XS row range
+// ---- XS build: unit id ((tile * 8 + slice) * n_win + window) and row of every edge of the XS row
+// range.  Edge-parallel: a workgroup takes kXsLabelChunk consecutive edges, finds the rows they
+// span by two binary searches of the offsets and keeps those offsets in LDS (every XS row has at
+// least kXsMinDegree edges, so a chunk spans a bounded number of rows).  A row-parallel walk is
+// bound by the longest row: 29 ms at scale 26, where one row has millions of edges.
+constexpr int kXsLabelChunk = 4096;
+constexpr int kXsLabelRows  = kXsLabelChunk + 2;  // rows of degree >= 1
+
 template <typename OffT>
-__global__ void xs_label_kernel(OffT const* __restrict__ offsets, int32_t const* __restrict__ indices,
-                                int64_t row_first, int64_t n_rows, int64_t e0,
-                                int32_t const* __restrict__ tile_of_row, int slice_shift, int n_win,
-                                int row_bits, int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge)
+__global__ __launch_bounds__(kThreads) void xs_label_kernel(
+  OffT const* __restrict__ offsets, int32_t const* __restrict__ indices, int64_t row_first, int64_t n_rows,
+  int64_t e0, int64_t n_edges, int32_t const* __restrict__ tile_of_row, int slice_shift, int n_win,
+  int row_bits, int32_t* __restrict__ unit, int32_t* __restrict__ row_of_edge,
+  int32_t const* __restrict__ tile_row, uint32_t* __restrict__ packed, int sub_bits)
 {
-  constexpr int G = 16;
-  int lane        = threadIdx.x & (G - 1);
-  int64_t group   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
-  int64_t groups  = ((int64_t)gridDim.x * blockDim.x) / G;
-  for (int64_t i = group; i < n_rows; i += groups) {
-    int64_t beg = static_cast<int64_t>(offsets[row_first + i]);
-    int64_t end = static_cast<int64_t>(offsets[row_first + i + 1]);
-    int32_t t   = tile_of_row[i];
-    for (int64_t j = beg + lane; j < end; j += G) {
-      uint32_t src   = static_cast<uint32_t>(indices[j]);
-      uint32_t slice = xs_slice_of(src, slice_shift);
-      uint32_t win   = xs_slice_local(src, slice_shift) >> (32 - row_bits);
-      unit[j - e0]   = (t * kXsSlices + static_cast<int32_t>(slice)) * n_win + static_cast<int32_t>(win);
-      row_of_edge[j - e0] = static_cast<int32_t>(i);
+  __shared__ int64_t s_off[kXsLabelRows];
+  __shared__ int64_t s_range[2];
+  OffT const* const off = offsets + row_first;  // off[i] - e0: first edge of XS row i
+  for (int64_t c0 = blockIdx.x * (int64_t)kXsLabelChunk; c0 < n_edges; c0 += (int64_t)gridDim.x * kXsLabelChunk) {
+    int64_t const c1 = c0 + kXsLabelChunk < n_edges ? c0 + kXsLabelChunk : n_edges;
+    if (threadIdx.x < 2) {
+      // last row that starts at or before the chunk's first / last edge
+      int64_t const target = e0 + (threadIdx.x == 0 ? c0 : c1 - 1);
+      int64_t lo = 0, hi = n_rows;  // invariant: off[lo] <= target < off[hi]
+      while (hi - lo > 1) {
+        int64_t const mid = (lo + hi) >> 1;
+        if (static_cast<int64_t>(off[mid]) <= target) lo = mid; else hi = mid;
+      }
+      s_range[threadIdx.x] = lo;
     }
+    __syncthreads();
+    int64_t const r_lo = s_range[0], r_hi = s_range[1];
+    int const n_r      = static_cast<int>(r_hi - r_lo) + 1;  // empty rows in between count too
+    bool const in_lds  = n_r + 1 <= kXsLabelRows;
+    if (in_lds)
+      for (int k = threadIdx.x; k <= n_r; k += blockDim.x) s_off[k] = static_cast<int64_t>(off[r_lo + k]) - e0;
+    __syncthreads();
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += blockDim.x) {
+      int lo = 0, hi = n_r;  // invariant: first edge of row r_lo + lo <= j < first edge of row r_lo + hi
+      while (hi - lo > 1) {
+        int const mid     = (lo + hi) >> 1;
+        int64_t const beg = in_lds ? s_off[mid] : static_cast<int64_t>(off[r_lo + mid]) - e0;
+        if (beg <= j) lo = mid; else hi = mid;
+      }
+      int64_t const i = r_lo + lo;
+      int32_t const t = tile_of_row[i];
+      uint32_t src    = static_cast<uint32_t>(indices[e0 + j]);
+      uint32_t slice  = xs_slice_of(src, slice_shift);
+      uint32_t win    = xs_slice_local(src, slice_shift) >> (32 - row_bits);
+      int32_t const u = (t * kXsSlices + static_cast<int32_t>(slice)) * n_win + static_cast<int32_t>(win);
+      if (packed) {
+        // the finished entry (unweighted graphs: nothing else travels with an edge); the sort
+        // columns are 2^sub_bits sub-units of the unit, by the top bits of the source position
+        uint32_t const low = xs_slice_local(src, slice_shift) & ((1u << (32 - row_bits)) - 1u);
+        packed[j]          = (low << row_bits) | static_cast<uint32_t>(i - tile_row[t]);
+        unit[j]            = (u << sub_bits) | static_cast<int32_t>(low >> (32 - row_bits - sub_bits));
+      } else {
+        unit[j]        = u;
+        row_of_edge[j] = static_cast<int32_t>(i);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1067,6 +1107,15 @@ __global__ void xs_payload_kernel(int32_t const* __restrict__ tile_of_row, int64
   for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u <= n_units;
        u += (int64_t)gridDim.x * blockDim.x)
     unit_off_out[u] = static_cast<int64_t>(unit_off_in[u]);
+}
+
+template <typename UOffT>
+__global__ void xs_unit_off_kernel(UOffT const* __restrict__ in, int64_t n_units, int sub_bits,
+                                   int64_t* __restrict__ out)
+{
+  for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u <= n_units;
+       u += (int64_t)gridDim.x * blockDim.x)
+    out[u] = static_cast<int64_t>(in[u << sub_bits]);
 }
 
 // debug aid (CUGRAPH_AMD_XS_VERIFY=1): entries of a unit must ascend by source
@@ -1634,37 +1683,68 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   flags.release();
   pos.release();
 
+  // Unweighted graphs: the packed entry itself is the sort key (inside a (tile, slice, window)
+  // unit it ascends with the source; 3 radix passes over 4-byte keys).  Weighted graphs sort
+  // (source, input position) pairs and fetch row and weight through the permutation.
+  bool const packed_keys = g.weights == nullptr && std::getenv("CUGRAPH_AMD_XS_SORT_PAIRS") == nullptr;
+  // Sort columns: a unit is cut into 2^sub_bits sub-units by the top bits of the source position,
+  // so the grouping pass does the first radix step (one pass less inside the columns) and the
+  // longest column -- the hot window of a hub tile, millions of entries for one workgroup -- is
+  // 2^sub_bits times shorter.
+  char const* sb_env = std::getenv("CUGRAPH_AMD_XS_SORT_SUBBITS");
+  int sub_bits       = packed_keys ? (sb_env ? std::atoi(sb_env) : 4) : 0;
+  if (sub_bits < 0 || sub_bits > 8) sub_bits = 0;
+  while (sub_bits > 0 && (n_units << sub_bits) >= 0x7fffffffLL) --sub_bits;
   DevBuf unit(static_cast<size_t>(ne) * 4), row_of_edge(static_cast<size_t>(ne) * 4);
-  hipLaunchKernelGGL((xs_label_kernel<OffT>), dim3(grid_for(n_rows * 16)), dim3(kThreads), 0, stream,
-                     offsets, g.indices, row_first, n_rows, e0, tile_of_row.as<int32_t>(), slice_shift,
-                     n_win, row_bits, unit.as<int32_t>(), row_of_edge.as<int32_t>());
+  int64_t const label_chunks = (ne + kXsLabelChunk - 1) / kXsLabelChunk;
+  hipLaunchKernelGGL((xs_label_kernel<OffT>), dim3(static_cast<unsigned>(std::min<int64_t>(label_chunks, 1 << 20))),
+                     dim3(kThreads), 0, stream,
+                     offsets, g.indices, row_first, n_rows, e0, ne, tile_of_row.as<int32_t>(), slice_shift,
+                     n_win, row_bits, unit.as<int32_t>(), row_of_edge.as<int32_t>(),
+                     plan.xs_tile_row.as<int32_t>(), packed_keys ? row_of_edge.as<uint32_t>() : nullptr, sub_bits);
   CGA_HIP(hipGetLastError());
-  // (entries of one source inside a unit go to different rows: their order does not matter)
-  CompressedOut c = compress_coo_perm(stream, n_units, g.minor_space(), ne, unit.as<int32_t>(),
-                                      g.indices + e0, false);
-  unit.release();
-  plan.xs_ent.alloc(static_cast<size_t>(ne + 4) * sizeof(uint32_t));
-  CGA_HIP(hipMemsetAsync(plan.xs_ent.p, 0, plan.xs_ent.bytes, stream));
-  if (g.weights) {
-    plan.xs_w.alloc(static_cast<size_t>(ne + 4) * sizeof(ValT));
-    CGA_HIP(hipMemsetAsync(plan.xs_w.p, 0, plan.xs_w.bytes, stream));
-  }
   plan.xs_unit_off.alloc(static_cast<size_t>(n_units + 1) * sizeof(int64_t));
-  auto launch = [&](auto tag) {
-    using UOffT = decltype(tag);
-    hipLaunchKernelGGL((xs_payload_kernel<OffT, UOffT, ValT>), dim3(grid_for(ne)), dim3(kThreads), 0,
-                       stream, tile_of_row.as<int32_t>(), e0, ne, c.perm.as<uint32_t>(),
-                       row_of_edge.as<int32_t>(), plan.xs_tile_row.as<int32_t>(),
-                       static_cast<ValT const*>(g.weights), c.offsets.as<UOffT>(), n_units,
-                       c.indices.as<int32_t>(), slice_shift, row_bits, plan.xs_ent.as<uint32_t>(),
-                       plan.xs_w.as<ValT>(), plan.xs_unit_off.as<int64_t>());
-  };
-  if (c.off64)
-    launch(int64_t{});
-  else
-    launch(int32_t{});
-  CGA_HIP(hipGetLastError());
-  CGA_HIP(hipStreamSynchronize(stream));
+  if (packed_keys) {
+    CompressedOut c = compress_coo_keys(stream, n_units << sub_bits, ne, unit.as<int32_t>(),
+                                        row_of_edge.as<uint32_t>(), row_bits, 32 - sub_bits);
+    unit.release();
+    row_of_edge.release();
+    plan.xs_ent = std::move(c.indices);  // ne + 4 entries, the last 4 zero
+    if (c.off64)
+      hipLaunchKernelGGL((xs_unit_off_kernel<int64_t>), dim3(grid_for(n_units + 1)), dim3(kThreads), 0, stream,
+                         c.offsets.as<int64_t>(), n_units, sub_bits, plan.xs_unit_off.as<int64_t>());
+    else
+      hipLaunchKernelGGL((xs_unit_off_kernel<int32_t>), dim3(grid_for(n_units + 1)), dim3(kThreads), 0, stream,
+                         c.offsets.as<int32_t>(), n_units, sub_bits, plan.xs_unit_off.as<int64_t>());
+    CGA_HIP(hipGetLastError());
+    CGA_HIP(hipStreamSynchronize(stream));
+  } else {
+    // (entries of one source inside a unit go to different rows: their order does not matter)
+    CompressedOut c = compress_coo_perm(stream, n_units, g.minor_space(), ne, unit.as<int32_t>(),
+                                        g.indices + e0, false);
+    unit.release();
+    plan.xs_ent.alloc(static_cast<size_t>(ne + 4) * sizeof(uint32_t));
+    CGA_HIP(hipMemsetAsync(plan.xs_ent.p, 0, plan.xs_ent.bytes, stream));
+    if (g.weights) {
+      plan.xs_w.alloc(static_cast<size_t>(ne + 4) * sizeof(ValT));
+      CGA_HIP(hipMemsetAsync(plan.xs_w.p, 0, plan.xs_w.bytes, stream));
+    }
+    auto launch = [&](auto tag) {
+      using UOffT = decltype(tag);
+      hipLaunchKernelGGL((xs_payload_kernel<OffT, UOffT, ValT>), dim3(grid_for(ne)), dim3(kThreads), 0,
+                         stream, tile_of_row.as<int32_t>(), e0, ne, c.perm.as<uint32_t>(),
+                         row_of_edge.as<int32_t>(), plan.xs_tile_row.as<int32_t>(),
+                         static_cast<ValT const*>(g.weights), c.offsets.as<UOffT>(), n_units,
+                         c.indices.as<int32_t>(), slice_shift, row_bits, plan.xs_ent.as<uint32_t>(),
+                         plan.xs_w.as<ValT>(), plan.xs_unit_off.as<int64_t>());
+    };
+    if (c.off64)
+      launch(int64_t{});
+    else
+      launch(int32_t{});
+    CGA_HIP(hipGetLastError());
+    CGA_HIP(hipStreamSynchronize(stream));
+  }
   if (std::getenv("CUGRAPH_AMD_XS_VERIFY")) {
     DevBuf out(24);
     CGA_HIP(hipMemsetAsync(out.p, 0, 24, stream));
@@ -2094,9 +2174,15 @@ struct Session {
   DevBuf hub_item_partial;
   Bucket buckets[kNumBuckets]{};
   std::vector<hipEvent_t> events;
+  // spmv_kernel beside xs_kernel on a stream of its own (see enqueue_iteration)
+  hipStream_t side_stream{nullptr};
+  hipEvent_t ev_fork{nullptr}, ev_join{nullptr};
   ~Session()
   {
     for (auto e : events) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
   }
 };
 
@@ -2518,6 +2604,17 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   }
 
   if (ev_kernel_begin) CGA_HIP(hipEventRecord(ev_kernel_begin, stream));
+  bool const beside = s.side_stream && s.xs_on && s.n_xs_blocks > 0 && phase == -1 && !raw_y;
+  auto launch_spmv = [&](hipStream_t st) {
+    if (g.weights)
+      hipLaunchKernelGGL((spmv_kernel<OffT, ValT, true>), dim3(s.n_spmv_blocks), dim3(kThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((spmv_kernel<OffT, ValT, false>), dim3(s.n_spmv_blocks), dim3(kThreads), 0, st, a);
+  };
+  if (beside) {
+    CGA_HIP(hipEventRecord(s.ev_fork, stream));
+    CGA_HIP(hipStreamWaitEvent(s.side_stream, s.ev_fork, 0));
+  }
   for (int region = 0; region < (split ? 2 : 1); ++region) {
     if (!(s.xs_on && s.n_xs_blocks > 0)) break;
     if ((region == 0 && phase == 1) || (region == 1 && phase == 0)) continue;
@@ -2540,13 +2637,12 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
   }
   // the dominant kernel: xs_kernel when the graph has XS tiles, else spmv_kernel
   if (ev_kernel_end && s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
-  // (spmv_kernel on a second stream beside xs_kernel was measured slower: 2.86 vs 2.74 ms)
-  if (g.weights)
-    hipLaunchKernelGGL((spmv_kernel<OffT, ValT, true>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
-                       stream, a);
-  else
-    hipLaunchKernelGGL((spmv_kernel<OffT, ValT, false>), dim3(s.n_spmv_blocks), dim3(kThreads), 0,
-                       stream, a);
+  if (beside) {
+    launch_spmv(s.side_stream);
+    CGA_HIP(hipEventRecord(s.ev_join, s.side_stream));
+  } else {
+    launch_spmv(stream);
+  }
   if (ev_kernel_end && !s.xs_on) CGA_HIP(hipEventRecord(ev_kernel_end, stream));
   if (s.n_hub_blocks > 0)
     hipLaunchKernelGGL((hub_finish_kernel<OffT, ValT>), dim3(s.n_hub_blocks), dim3(kThreads), 0,
@@ -2559,6 +2655,7 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     CGA_HIP(hipGetLastError());
     return;
   }
+  if (beside) CGA_HIP(hipStreamWaitEvent(stream, s.ev_join, 0));
   if (s.n_pers_blocks > 0)
     hipLaunchKernelGGL((pers_fix_kernel<ValT>), dim3(s.n_pers_blocks), dim3(kThreads), 0, stream,
                        s.pers_v.as<int32_t>(), s.pers_p.as<ValT>(), s.n_pers, a.pr_old, a.pr_new,
@@ -2609,6 +2706,13 @@ Session* session_create(Handle const& h, Graph& g, PagerankArgs const& a)
       session_setup<double>(*s, a);
     else
       session_setup<float>(*s, a);
+    if (char const* e = std::getenv("CUGRAPH_AMD_SPMV_BESIDE"); e && std::atoi(e) != 0 && s->xs_on) {
+      int lo = 0, hi = 0;
+      CGA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo: the least urgent
+      CGA_HIP(hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, std::atoi(e) == 2 ? lo : hi));
+      CGA_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+      CGA_HIP(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
   } catch (...) {
     delete s;
     throw;

@@ -9,7 +9,7 @@
 //     while the ids span less than 2^31; wider id spaces (hashed 64-bit ids) go through an
 //     open-addressing hash set of the distinct ids, which are then sorted and searched;
 //   - degrees come from the same histogram kernel as the CSC build;
-//   - the order is a stable LSD radix split, one bit per pass (flag + scan + scatter), so the
+//   - the order is a stable LSD radix sort, 8 bits per pass (count + scan + scatter), so the
 //     result is deterministic;
 //   - relabelling is a table lookup.
 // Degree-descending order is what gives the SpMV contiguous degree buckets (the reference's
@@ -54,27 +54,6 @@ __global__ void iota_kernel(int32_t* v, int64_t n) { GRID_STRIDE(i, n) v[i] = (i
 __global__ void fill_u64_kernel(unsigned long long* v, int64_t n, unsigned long long value)
 {
   GRID_STRIDE(i, n) v[i] = value;
-}
-
-__global__ void bit_flag_kernel(unsigned int const* keys, int64_t n, int bit, unsigned int* flags)
-{
-  GRID_STRIDE(i, n) flags[i] = (keys[i] >> bit) & 1u;
-}
-
-// stable split, ones first (descending order)
-__global__ void bit_split_kernel(unsigned int const* keys_in, int32_t const* vals_in, int64_t n,
-                                 int bit, int64_t const* ones_before, unsigned int* keys_out,
-                                 int32_t* vals_out)
-{
-  int64_t total_ones = ones_before[n];
-  GRID_STRIDE(i, n)
-  {
-    unsigned int k = keys_in[i];
-    int64_t ob     = ones_before[i];
-    int64_t pos    = ((k >> bit) & 1u) ? ob : total_ones + (i - ob);
-    keys_out[pos]  = k;
-    vals_out[pos]  = vals_in[i];
-  }
 }
 
 __global__ void gather_u32_kernel(unsigned int const* in, int32_t const* order, int64_t n, unsigned int* out)
@@ -430,6 +409,89 @@ void degree_order_sources_first(hipStream_t stream, unsigned int const* deg, int
   degree_order(stream, keys.as<unsigned int>(), n, order, rank);
 }
 
+// ---- stable LSD radix sort of (key, value) pairs, descending keys, 8 bits per pass over many
+// workgroups: per-tile digit counts (digit-major, so one exclusive scan gives every tile's first
+// output position of every digit), then a scatter that ranks the keys of a tile in input order.
+constexpr int kRsThreads = 256;
+constexpr int kRsRounds  = 16;
+constexpr int kRsTile    = kRsThreads * kRsRounds;
+
+// lanes of the wave that hold the same digit as this one (valid lanes only)
+__device__ inline unsigned long long same_digit_lanes(unsigned int d, bool valid)
+{
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    unsigned long long const bal = __ballot(valid && ((d >> bit) & 1u));
+    m &= ((d >> bit) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(kRsThreads) void radix_count_kernel(unsigned int const* __restrict__ keys, int64_t n,
+                                                                 int shift, int64_t n_tiles,
+                                                                 unsigned int* __restrict__ counts)
+{
+  __shared__ unsigned int cnt[256];
+  int const lane = threadIdx.x & 63;
+  unsigned long long const below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  int64_t const base = blockIdx.x * (int64_t)kRsTile;
+  for (int r = 0; r < kRsRounds; ++r) {
+    int64_t const i      = base + r * kRsThreads + threadIdx.x;
+    bool const valid     = i < n;
+    unsigned int const d = 255u - ((valid ? keys[i] >> shift : 0u) & 255u);  // descending
+    // (degrees are skewed: most keys of a tile share a digit, so one LDS atomic per wave and digit)
+    unsigned long long const m = same_digit_lanes(d, valid);
+    if (valid && (m & below) == 0ull) atomicAdd(&cnt[d], static_cast<unsigned int>(__popcll(m)));
+  }
+  __syncthreads();
+  counts[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kRsThreads) void radix_scatter_kernel(
+  unsigned int const* __restrict__ keys_in, int32_t const* __restrict__ vals_in, int64_t n, int shift,
+  int64_t n_tiles, int64_t const* __restrict__ first_pos, unsigned int* __restrict__ keys_out,
+  int32_t* __restrict__ vals_out)
+{
+  __shared__ int64_t run[256];  // next output position of every digit
+  __shared__ int64_t wave_pos[kRsThreads / 64][256];
+  __shared__ unsigned int wave_cnt[kRsThreads / 64][256];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long const below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  run[threadIdx.x] = first_pos[threadIdx.x * n_tiles + blockIdx.x];
+  int64_t const base = blockIdx.x * (int64_t)kRsTile;
+  for (int r = 0; r < kRsRounds; ++r) {
+    int64_t const i  = base + r * kRsThreads + threadIdx.x;  // round-major: input order
+    bool const valid = i < n;
+#pragma unroll
+    for (int w = 0; w < kRsThreads / 64; ++w) wave_cnt[w][threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned int const k = valid ? keys_in[i] : 0u;
+    unsigned int const d = 255u - ((k >> shift) & 255u);
+    unsigned long long const m = same_digit_lanes(d, valid);
+    int const rank = __popcll(m & below);
+    if (valid && rank == 0) wave_cnt[wave][d] = static_cast<unsigned int>(__popcll(m));
+    __syncthreads();
+    {  // thread = digit: where each wave's keys of this digit start
+      int64_t p = run[threadIdx.x];
+#pragma unroll
+      for (int w = 0; w < kRsThreads / 64; ++w) {
+        wave_pos[w][threadIdx.x] = p;
+        p += wave_cnt[w][threadIdx.x];
+      }
+      run[threadIdx.x] = p;
+    }
+    __syncthreads();
+    if (valid) {
+      int64_t const p = wave_pos[wave][d] + rank;
+      keys_out[p]     = k;
+      vals_out[p]     = vals_in[i];
+    }
+  }
+}
+
 // order[new] = old, rank[old] = new; stable, descending degree
 void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf& order, DevBuf& rank)
 {
@@ -437,7 +499,9 @@ void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf
   order.alloc(nn * sizeof(int32_t));
   rank.alloc(nn * sizeof(int32_t));
   if (n == 0) return;
-  DevBuf keys_a(nn * 4), keys_b(nn * 4), vals_b(nn * 4), flags(nn * 4), pos((nn + 1) * 8), mx(4);
+  int64_t const n_tiles = (n + kRsTile - 1) / kRsTile;
+  size_t const n_counts = static_cast<size_t>(n_tiles) * 256;
+  DevBuf keys_a(nn * 4), keys_b(nn * 4), vals_b(nn * 4), counts(n_counts * 4), pos((n_counts + 1) * 8), mx(4);
   CGA_HIP(hipMemcpyAsync(keys_a.p, deg, nn * 4, hipMemcpyDeviceToDevice, stream));
   CGA_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
   hipLaunchKernelGGL(max_u32_kernel, dim3(grid_for(n, 1024)), dim3(kThreads), 0, stream, deg, n,
@@ -451,12 +515,12 @@ void degree_order(hipStream_t stream, unsigned int const* deg, int64_t n, DevBuf
   int32_t* vin       = order.as<int32_t>();
   int32_t* vout      = vals_b.as<int32_t>();
   int bits           = bit_width_u32(h_max);
-  for (int b = 0; b < bits; ++b) {
-    hipLaunchKernelGGL(bit_flag_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, kin, n, b,
-                       flags.as<unsigned int>());
-    exclusive_scan_u32_to_i64(stream, flags.as<unsigned int>(), n, pos.as<int64_t>());
-    hipLaunchKernelGGL(bit_split_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, kin, vin, n,
-                       b, pos.as<int64_t>(), kout, vout);
+  for (int shift = 0; shift < bits; shift += 8) {
+    hipLaunchKernelGGL(radix_count_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kRsThreads), 0, stream, kin,
+                       n, shift, n_tiles, counts.as<unsigned int>());
+    exclusive_scan_u32_to_i64(stream, counts.as<unsigned int>(), static_cast<int64_t>(n_counts), pos.as<int64_t>());
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kRsThreads), 0, stream,
+                       kin, vin, n, shift, n_tiles, pos.as<int64_t>(), kout, vout);
     std::swap(kin, kout);
     std::swap(vin, vout);
   }
