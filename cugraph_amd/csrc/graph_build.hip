@@ -347,11 +347,14 @@ __global__ void sort_small_kernel(OffT const* __restrict__ offsets, KeyT* __rest
 
 constexpr int kMedCap = 8192;  // keys per workgroup-sorted column (64 KiB of LDS at 8-byte keys)
 
+constexpr int kWaveCap = 1024;  // keys per wave-sorted column (16 registers a lane)
+
 template <typename OffT>
 __global__ void classify_columns_kernel(OffT const* __restrict__ offsets, int64_t n_major,
                                         int32_t* __restrict__ med_list,
                                         int32_t* __restrict__ big_list,
-                                        unsigned int* __restrict__ n_lists /* [2] */)
+                                        int32_t* __restrict__ wave_list,
+                                        unsigned int* __restrict__ n_lists /* [3] */)
 {
   // one atomic per wave and list: the lanes that append share a reservation
   int const lane = threadIdx.x & 63;
@@ -361,8 +364,14 @@ __global__ void classify_columns_kernel(OffT const* __restrict__ offsets, int64_
   for (int64_t r = 0; r < rounds; ++r) {
     int64_t v   = r * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int64_t deg = v < n_major ? static_cast<int64_t>(offsets[v + 1] - offsets[v]) : 0;
-    bool const med = deg > 64 && deg <= kMedCap, big = deg > kMedCap;
-    unsigned long long const m_med = __ballot(med), m_big = __ballot(big);
+    bool const med = deg > kWaveCap && deg <= kMedCap, big = deg > kMedCap, wav = deg > 64 && deg <= kWaveCap;
+    unsigned long long const m_med = __ballot(med), m_big = __ballot(big), m_wav = __ballot(wav);
+    if (m_wav) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(&n_lists[2], static_cast<unsigned int>(__popcll(m_wav)));
+      base = __shfl(base, 0, 64);
+      if (wav) wave_list[base + __popcll(m_wav & below)] = static_cast<int32_t>(v);
+    }
     if (m_med) {
       unsigned int base = 0;
       if (lane == 0) base = atomicAdd(&n_lists[0], static_cast<unsigned int>(__popcll(m_med)));
@@ -375,6 +384,69 @@ __global__ void classify_columns_kernel(OffT const* __restrict__ offsets, int64_
       base = __shfl(base, 0, 64);
       if (big) big_list[base + __popcll(m_big & below)] = static_cast<int32_t>(v);
     }
+  }
+}
+
+// One wave per column of 65 .. kWaveCap keys: a bitonic network over R keys a lane (key i of the
+// column in register i / 64 of lane i % 64), partners 64 or more apart are registers of the same
+// lane, nearer ones come by DPP / shuffle.  No LDS, no barriers: the workgroup version below spends
+// its time in 28 barriers for a 128-key column with three of its four waves idle.
+template <typename KeyT, int R>
+__device__ inline void wave_bitonic(KeyT* __restrict__ col, int deg, int lane)
+{
+  KeyT k[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) k[r] = r * 64 + lane < deg ? col[r * 64 + lane] : key_max<KeyT>();
+#pragma unroll
+  for (int size = 2; size <= R * 64; size <<= 1) {
+#pragma unroll
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & (j >> 6)) == 0) {
+            int const q   = r | (j >> 6);
+            bool const up = ((r * 64) & size) == 0;
+            KeyT const a = k[r], b = k[q];
+            bool const sw = (a > b) == up;
+            k[r]          = sw ? b : a;
+            k[q]          = sw ? a : b;
+          }
+        }
+      } else {
+        bool const lower = (lane & j) == 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          KeyT const o  = __shfl_xor(k[r], j, 64);
+          bool const up = ((r * 64 + lane) & size) == 0;
+          KeyT const mn = k[r] < o ? k[r] : o, mx = k[r] < o ? o : k[r];
+          k[r]          = (lower == up) ? mn : mx;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r * 64 + lane < deg) col[r * 64 + lane] = k[r];
+}
+
+template <typename OffT, typename KeyT>
+__global__ __launch_bounds__(256) void sort_wave_kernel(OffT const* __restrict__ offsets, KeyT* __restrict__ keys,
+                                                        int32_t const* __restrict__ list,
+                                                        unsigned int const* __restrict__ n_list)
+{
+  int const lane         = threadIdx.x & 63;
+  unsigned int const wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  unsigned int const n_cols = *n_list;
+  for (unsigned int c = wid; c < n_cols; c += n_waves) {
+    int32_t const v = list[c];
+    OffT const b    = offsets[v];
+    int const deg   = __builtin_amdgcn_readfirstlane(static_cast<int>(offsets[v + 1] - b));
+    KeyT* col       = keys + b;
+    if (deg <= 128) wave_bitonic<KeyT, 2>(col, deg, lane);
+    else if (deg <= 256) wave_bitonic<KeyT, 4>(col, deg, lane);
+    else if (deg <= 512) wave_bitonic<KeyT, 8>(col, deg, lane);
+    else wave_bitonic<KeyT, 16>(col, deg, lane);
   }
 }
 
@@ -589,14 +661,20 @@ void order_columns(hipStream_t stream, OffT const* offsets, KeyT* keys, int64_t 
   // lists of the longer columns
   int64_t max_long = n_edges / 65 + 1;
   if (max_long > n_major) max_long = n_major;
-  DevBuf med(max_long * sizeof(int32_t)), big(max_long * sizeof(int32_t)), counts(2 * sizeof(unsigned int));
-  CGA_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned int), stream));
+  DevBuf med(max_long * sizeof(int32_t)), big(max_long * sizeof(int32_t)), wav(max_long * sizeof(int32_t)),
+    counts(3 * sizeof(unsigned int));
+  CGA_HIP(hipMemsetAsync(counts.p, 0, 3 * sizeof(unsigned int), stream));
   hipLaunchKernelGGL((classify_columns_kernel<OffT>), dim3(grid_for(n_major)), dim3(kThreads), 0,
-                     stream, offsets, n_major, med.as<int32_t>(), big.as<int32_t>(),
+                     stream, offsets, n_major, med.as<int32_t>(), big.as<int32_t>(), wav.as<int32_t>(),
                      counts.as<unsigned int>());
-  unsigned int h_counts[2];
+  unsigned int h_counts[3];
   CGA_HIP(hipMemcpyAsync(h_counts, counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
+  if (h_counts[2] > 0) {
+    int64_t const blocks = (static_cast<int64_t>(h_counts[2]) + 3) / 4;  // 4 waves a workgroup
+    hipLaunchKernelGGL((sort_wave_kernel<OffT, KeyT>), dim3(static_cast<unsigned>(std::min<int64_t>(blocks, 1 << 16))),
+                       dim3(256), 0, stream, offsets, keys, wav.as<int32_t>(), counts.as<unsigned int>() + 2);
+  }
   if (h_counts[0] > 0) {
     int grid = h_counts[0] < 2048u ? (int)h_counts[0] : 2048;
     hipLaunchKernelGGL((sort_medium_kernel<OffT, KeyT>), dim3(grid), dim3(256), 0, stream, offsets,
