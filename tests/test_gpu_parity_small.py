@@ -177,8 +177,8 @@ def test_rmat_pagerank_vs_oracle(scale, dtype, weighted, xs_tiles, monkeypatch):
 
 @pytest.mark.parametrize("tile_edges,piece", [(65536, 1024), (1 << 30, 300), (4096, 1 << 20), (1 << 20, 1 << 14)])
 @pytest.mark.parametrize("scale,dtype,weighted", [(16, np.float32, False), (14, np.float64, True)])
-@pytest.mark.parametrize("compact,row_bits,search", [("0", "12", False), ("1", "13", True), ("1", "14", False)])
-def test_xs_work_items_cut_into_pieces(tile_edges, piece, scale, dtype, weighted, compact, row_bits, search,
+@pytest.mark.parametrize("compact,row_bits,sub_bits", [("0", "12", "0"), ("1", "13", "8"), ("1", "14", None)])
+def test_xs_work_items_cut_into_pieces(tile_edges, piece, scale, dtype, weighted, compact, row_bits, sub_bits,
                                        monkeypatch):
     """The XS work-item machinery at sizes a test can hold: tiles cut into up to 15 pieces (each
     with partials of its own), one tile holding every row, tiles of a few rows -- all must give the
@@ -192,9 +192,9 @@ def test_xs_work_items_cut_into_pieces(tile_edges, piece, scale, dtype, weighted
     # single-GPU compact source space (slots only for vertices with out-edges) and the wider tiles
     monkeypatch.setenv("CUGRAPH_AMD_COMPACT", compact)
     monkeypatch.setenv("CUGRAPH_AMD_XS_ROWBITS", row_bits)
-    # the window of an entry by binary search of the record, as graphs with more than 16 windows do
-    if search:
-        monkeypatch.setenv("CUGRAPH_AMD_XS_SEARCH_WINDOWS", "1")
+    # plan build of unweighted graphs: the units sorted whole, or as 256 sub-unit columns each (default 16)
+    if sub_bits is not None:
+        monkeypatch.setenv("CUGRAPH_AMD_XS_SORT_SUBBITS", sub_bits)
     nv, ne = 1 << scale, 16 << scale
     src, dst = oracle.rmat_edges(scale, ne, seed=7)
     wgt = oracle.rmat_weights(ne, seed=8).astype(dtype) if weighted else None
