@@ -45,6 +45,9 @@ def parse():
                    help="skip BASELINE configs C2 (scale 22) and C3 (scale 24 fp64 weighted personalized)")
     p.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                    help="gloo: CPU ranks, only with --engine test-double (a rehearsal of the launcher and driver)")
+    p.add_argument("--share-device", action="store_true",
+                   help="REHEARSAL of the multi-rank path on a one-GPU machine: every rank runs its HIP sessions on "
+                        "device 0 and the collectives go over gloo; the line it prints is marked as not a measurement")
     p.add_argument("--engine", default="hip", choices=("hip", "test-double"),
                    help="test-double: the numpy stand-in of tests/mg_test_double.py instead of the HIP library; "
                         "measures nothing -- it exists so that the multi-rank launch path can be run without GPUs")
@@ -312,10 +315,14 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if os.environ.get("CUGRAPH_AMD_BENCH_DUMP_AFTER"):  # a rank that stops making progress says where, and exits
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["CUGRAPH_AMD_BENCH_DUMP_AFTER"]), exit=True)
     if args.engine == "test-double":
         return main_test_double(args)
-    if args.backend != "nccl":
-        raise SystemExit("--backend gloo runs CPU ranks: it needs --engine test-double")
+    if args.backend != "nccl" and not args.share_device:
+        raise SystemExit("--backend gloo runs CPU ranks: it needs --engine test-double (or --share-device)")
     # libraries (RCCL's banner, ...) write to the C-level stdout: keep fd 1 for the one JSON line
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -329,9 +336,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: let bench.py start its ranks itself "
                          f"(no WORLD_SIZE in the environment) or launch {args.gpus} ranks")
     n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-    if n_dev < world:
+    if n_dev < world and not args.share_device:
         raise SystemExit(f"bench.py --gpus {world} needs {world} devices, one per rank: this machine has {n_dev}")
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    device_index = local_rank if world > 1 and not args.share_device else 0
+    torch.cuda.set_device(device_index)
 
     from cugraph_amd import generators, pylibcugraph as plc
     from cugraph_amd.session import PagerankSession
@@ -347,8 +355,11 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
 
     handle = plc.ResourceHandle(rank=rank, comm_size=world) if use_mg else plc.ResourceHandle()
     props = plc.GraphProperties(is_symmetric=False, is_multigraph=True)
@@ -404,7 +415,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
@@ -514,6 +525,9 @@ def main():
         "buckets": {k: info[k] for k in ("low_degree_vertices", "mid_degree_vertices", "hub_vertices",
                                          "spmv_workgroups")},
     }
+    if args.share_device:
+        out["rehearsal"] = (f"{world} ranks SHARING one GPU, collectives over gloo through the host: exercises the "
+                            "multi-rank code path, its timings are not a measurement")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sess = None
         graph = None

@@ -78,7 +78,7 @@ def edge_balanced_bounds(dst, num_vertices, world, group=None, coarse_buckets=1 
     nb = -(-nv // width)
     d64 = dst.to(torch.int64)
     hist = torch.bincount(torch.div(d64, width, rounding_mode="floor"), minlength=nb).to(torch.int64)
-    dist.all_reduce(hist, group=group)
+    all_reduce(hist, group)
     prefix = torch.cumsum(hist, 0).cpu().numpy()  # edges of buckets 0..b
     total = int(prefix[-1]) if nb else 0
     if total == 0:
@@ -93,7 +93,7 @@ def edge_balanced_bounds(dst, num_vertices, world, group=None, coarse_buckets=1 
             lo = b * width
             inside = d64[(d64 >= lo) & (d64 < lo + width)] - lo
             fine[i] = torch.bincount(inside, minlength=width)
-        dist.all_reduce(fine, group=group)
+        all_reduce(fine, group)
         fine = fine.cpu().numpy()
     bounds = [0]
     for i, (t, b) in enumerate(zip(targets, cut_bucket)):
@@ -129,9 +129,48 @@ def _dist():
     return dist
 
 
+def _gather_through_host(x_full, chunk, rank, world, group):
+    """gloo with device tensors (ranks of a rehearsal sharing one GPU): its flat in-place form
+    never completes there, so the chunks travel as host copies."""
+    import torch
+
+    mine = x_full[rank * chunk:(rank + 1) * chunk].cpu()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    _dist().all_gather(parts, mine, group=group)
+    x_full[:chunk * world].copy_(torch.cat(parts))
+
+
+def _gloo_on_device(t, group):
+    return t.is_cuda and _dist().get_backend(group) == "gloo"
+
+
+def all_reduce(t, group=None, op=None):
+    """In-place all-reduce (sum by default); device tensors over gloo travel as host copies."""
+    dist = _dist()
+    op = dist.ReduceOp.SUM if op is None else op
+    if _gloo_on_device(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def all_to_all_single(out, a, out_split=None, in_split=None, group=None):
+    dist = _dist()
+    if _gloo_on_device(a, group):
+        h = out.cpu()
+        dist.all_to_all_single(h, a.cpu(), output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        out.copy_(h)
+    else:
+        dist.all_to_all_single(out, a, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+
+
 def all_gather_in_place(x_full, chunk, rank, world, group=None):
     """x_full[r*chunk:(r+1)*chunk] of every rank -> x_full of every rank."""
     dist = _dist()
+    if _gloo_on_device(x_full, group):
+        return _gather_through_host(x_full, chunk, rank, world, group)
     mine = x_full[rank * chunk:(rank + 1) * chunk]
     try:
         dist.all_gather_into_tensor(x_full, mine, group=group)
@@ -152,6 +191,9 @@ def all_gather_region_async(region, sub_chunk, rank, world, group=None):
     the r-th), started without waiting: returns a handle whose wait() orders the current stream
     behind it."""
     dist = _dist()
+    if _gloo_on_device(region, group):
+        _gather_through_host(region, sub_chunk, rank, world, group)
+        return _Done()
     mine = region[rank * sub_chunk:(rank + 1) * sub_chunk]
     try:
         return dist.all_gather_into_tensor(region, mine, group=group, async_op=True)
@@ -169,18 +211,22 @@ def shuffle_edges_to_owner(src, dst, wgt, bounds, world, group=None):
     dist = _dist()
     inner = torch.as_tensor(bounds[1:-1], dtype=torch.int64, device=dst.device)
     owner = torch.bucketize(dst.to(torch.int64), inner, right=True)
-    order = torch.argsort(owner, stable=True)
+    # edges grouped by owner, input order kept: one compaction per owner (a stable sort of E keys
+    # for a handful of distinct values is the slower way to say the same)
+    if world <= 64:
+        order = torch.cat([torch.nonzero(owner == p).flatten() for p in range(world)])
+    else:
+        order = torch.argsort(owner, stable=True)
     send_counts = torch.bincount(owner, minlength=world)
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    all_to_all_single(recv_counts, send_counts, group=group)
     in_split = [int(c) for c in send_counts.tolist()]
     out_split = [int(c) for c in recv_counts.tolist()]
 
     def route(a):
         a = a[order].contiguous()
         out = torch.empty(sum(out_split), dtype=a.dtype, device=a.device)
-        dist.all_to_all_single(out, a, output_split_sizes=out_split, input_split_sizes=in_split,
-                               group=group)
+        all_to_all_single(out, a, out_split, in_split, group)
         return out
 
     return route(src), route(dst), (None if wgt is None else route(wgt))
@@ -316,9 +362,9 @@ class MGPagerank:
         counts = engine.source_weight_sums(src, None, self.num_vertices)
         sums = counts if wgt is None else engine.source_weight_sums(src, wgt, self.num_vertices)
         if world > 1:
-            dist.all_reduce(counts, group=group)
+            all_reduce(counts, group)
             if wgt is not None:
-                dist.all_reduce(sums, group=group)
+                all_reduce(sums, group)
         # rows: descending in-degree inside the owned range
         self.order, self.rank_local = engine.degree_order(dst, self.first, self.last)
         own_counts = counts[self.first:self.last]
@@ -332,7 +378,7 @@ class MGPagerank:
             active = own_counts[order] > 0
             n_active = torch.count_nonzero(active).reshape(1).to(torch.int64)
             if world > 1:
-                dist.all_reduce(n_active, op=dist.ReduceOp.MAX, group=group)
+                all_reduce(n_active, group, dist.ReduceOp.MAX)
             self.slot_chunk = max(int(n_active.item()), 1)
             self.regions = self._choose_regions(engine, self.slot_chunk, world)
             j = torch.cumsum(active, 0) - 1  # index of a row among this rank's sources
@@ -354,7 +400,7 @@ class MGPagerank:
         # the slots are assigned again afterwards, which is a collective)
         n_edges_all = torch.tensor([src.numel()], dtype=torch.int64, device=src.device)
         if world > 1:
-            dist.all_reduce(n_edges_all, group=group)
+            all_reduce(n_edges_all, group)
         env = os.environ.get("CUGRAPH_AMD_RENUMBER_LOCALITY")
         if env == "1" or (env is None and int(n_edges_all.item()) >= (1 << 22)):
             rows = self.rank_local[(dst - self.first).long()].long()
@@ -483,7 +529,7 @@ class MGPagerank:
             return v, x
         sizes = torch.zeros(self.world, dtype=torch.int64, device=dev)
         sizes[self.rank] = v.numel()
-        dist.all_reduce(sizes, group=self.group)
+        all_reduce(sizes, self.group)
         longest = int(sizes.max())
         if longest == 0:
             return v, x
@@ -576,7 +622,7 @@ class MGPagerank:
         # which the next iteration's kernels read.  An iteration skipped after the stop leaves
         # scal[2:4] alone, so summing again gives the same scal[0:2] (never P times the last one).
         total = scal[2:4].clone()
-        _dist().all_reduce(total, group=self.group)
+        all_reduce(total, self.group)
         scal[0:2].copy_(total)
         if self.regions is None:
             return (all_gather_region_async(x_full[:self.slot_chunk * self.world], self.slot_chunk, self.rank,

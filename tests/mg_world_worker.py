@@ -19,8 +19,18 @@ def main():
     scale = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     weighted = len(sys.argv) > 2 and sys.argv[2] == "weighted"
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    # rehearsal on a one-GPU box: every rank on device 0, collectives over gloo (staged through the host)
+    shared = os.environ.get("CUGRAPH_AMD_TEST_SHARED_GPU") == "1"
+    if os.environ.get("CUGRAPH_AMD_TEST_DUMP_AFTER"):  # where a rank is stuck, instead of a silent hang
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["CUGRAPH_AMD_TEST_DUMP_AFTER"]), exit=True)
+    if shared:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     try:
         nv, ne = 1 << scale, 16 << scale
         src, dst = oracle.rmat_edges(scale, ne, seed=9, scramble=True)
