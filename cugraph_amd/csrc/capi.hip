@@ -1119,4 +1119,18 @@ void cugraph_amd_pagerank_session_free(cugraph_amd_pagerank_session_t* session)
 
 const char* cugraph_amd_version(void) { return "cugraph_amd 0.1 (gfx950)"; }
 
+#ifdef CGA_TIMING_AIDS
+// timing-aid build only (make AIDS=1; not in include/cugraph_amd_c.h): out[0] = gathers of region-0
+// launches of xs_kernel that read beyond the region, out[1] = region-0 launches checked
+int cugraph_amd_aids_region_check(unsigned long long out[2])
+{
+  try {
+    cga::xs_region_check_read(out);
+    return 0;
+  } catch (...) {
+    return 1;
+  }
+}
+#endif
+
 }  // extern "C"

@@ -98,6 +98,7 @@ struct XsArgs {
   int profile;           // per-workgroup times into xs_prof_buf
   uint32_t gather_mask;  // narrows every gathered index (results are then wrong)
   int no_atomics;        // row sums are not accumulated (one add per lane and pass keeps the loads alive)
+  uint32_t slot_limit;   // region 0 of a partitioned graph: gathers at or beyond it are counted (0: no check)
 #endif
 };
 
@@ -534,6 +535,9 @@ struct XsLaunch {
 #ifdef CGA_TIMING_AIDS
 // per-workgroup times (make AIDS=1; CUGRAPH_AMD_XS_PROFILE=1)
 __device__ unsigned long long xs_prof_buf[1024 * 8];
+// gathers of a region-0 launch that read a slot of region 1 (the all-gather of region 1 may still
+// be running then: there must be none), and the region-0 launches checked
+__device__ unsigned long long xs_region_check[2];
 #define CGA_XSP(stmt) do { if (a.xs.profile) { stmt; } } while (0)
 #else
 #define CGA_XSP(stmt) do { } while (0)
@@ -711,6 +715,9 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
           // an entry that is not the item's was clamped to the item's last one, but its window was
           // counted from its own position: the slot may not exist.  Slot 0 always does.
           if constexpr (!FAST) gi = p[e] ? gi : 0u;
+#ifdef CGA_TIMING_AIDS
+          if (a.xs.slot_limit != 0u && gi >= a.xs.slot_limit) atomicAdd(&xs_region_check[0], 1ull);
+#endif
           xv[e] = a.x_cur[CGA_GMASK(a.xs, gi)];
         }
         uint32_t en_next[EPL];
@@ -825,6 +832,8 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
 }
 
 #ifdef CGA_TIMING_AIDS
+__global__ void xs_region_count_kernel() { xs_region_check[1] += 1ull; }
+
 __global__ void xs_prof_dump_kernel(int n)
 {
   for (int i = 0; i < n; ++i) {
@@ -1498,6 +1507,16 @@ inline int grid_for(int64_t items, int cap = 256 * 16)
 }
 
 }  // namespace
+
+#ifdef CGA_TIMING_AIDS
+// (make AIDS=1) {gathers of region-0 launches beyond the region, region-0 launches checked} so far
+void xs_region_check_read(unsigned long long* out)
+{
+  CGA_HIP(hipDeviceSynchronize());
+  CGA_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(xs_region_check), 2 * sizeof(unsigned long long)));
+}
+
+#endif
 
 // implemented in graph_build.hip (reused here for stream compaction)
 void exclusive_scan_u32_to_i64(hipStream_t stream, unsigned int const* counts, int64_t n,
@@ -2623,6 +2642,10 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.rec      = plan.xs_rec[region].as<int64_t>();
     a.xs.n_items  = plan.xs_n_items[region];
     a.xs.counters = s.xs_counters.as<int>() + kXsSlices * region;
+#ifdef CGA_TIMING_AIDS
+    a.xs.slot_limit = split && region == 0 ? static_cast<uint32_t>(g.hot_slots) : 0u;
+    if (a.xs.slot_limit != 0u) hipLaunchKernelGGL(xs_region_count_kernel, dim3(1), dim3(1), 0, stream);
+#endif
     XsLaunch<ValT> xl{a.xs, a.x_cur, a.scal, a.ctrl, a.epsilon};
     auto kern = reinterpret_cast<void (*)(XsLaunch<ValT>)>(s.xs_kernel_fn);
     hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(s.xs_threads), s.xs_lds_bytes, stream, xl);

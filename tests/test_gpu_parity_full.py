@@ -6,10 +6,14 @@ personalization) are small enough for the CPU oracle: ranks within north_star's 
 is checked through size-independent properties: the CSC against checksums of the edge list, mass
 conservation, the fixed point, and agreement of the two independent SpMV paths (XS tiles vs
 degree buckets)."""
+import os
+
 import numpy as np
 import pytest
 
 from helpers import compressed_tensors, to_dev
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 pytestmark = pytest.mark.gpu
 
@@ -485,3 +489,33 @@ def test_two_regions_of_the_gathered_vector(monkeypatch):
         got[first + orders[r].cpu().numpy()] = vals.cpu().numpy()
     assert conv_b and iters_b == iters
     assert np.max(np.abs(got - want)) <= 1e-7
+    # the timing-aid build (make AIDS=1, CUGRAPH_AMD_LIBRARY) counts the gathers of region-0 launches
+    # that read a slot of region 1 -- whose all-gather may still be running then: there must be none
+    import ctypes
+    from cugraph_amd import _capi
+
+    lib = _capi.load()
+    if hasattr(lib, "cugraph_amd_aids_region_check"):
+        out = (ctypes.c_ulonglong * 2)()
+        assert lib.cugraph_amd_aids_region_check(out) == 0
+        print(f"region check: {out[0]} gathers beyond region 0 in {out[1]} region-0 launches")
+        assert out[1] > 0 and out[0] == 0
+
+
+def test_phase_0_reads_only_the_hot_region():
+    """The test above under the timing-aid library, whose xs_kernel counts every gather of a
+    region-0 launch that lands at or beyond hot_slots (the advisor's debug assertion: phase 0 runs
+    while region 1 is still being gathered)."""
+    import os
+    import subprocess
+    import sys
+
+    aids = os.path.join(os.path.dirname(HERE), "cugraph_amd", "libcugraph_amd_c_aids.so")
+    if not os.path.exists(aids):
+        pytest.skip("timing-aid library not built (make -C cugraph_amd/csrc AIDS=1)")
+    env = dict(os.environ, CUGRAPH_AMD_LIBRARY=aids)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "--timeout", "300", "--timeout-method",
+                        "thread", f"{os.path.abspath(__file__)}::test_two_regions_of_the_gathered_vector"],
+                       capture_output=True, text=True, timeout=400, env=env, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "region check: 0 gathers beyond region 0" in r.stdout
