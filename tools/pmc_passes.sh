@@ -2,6 +2,8 @@
 # calibration of FETCH_SIZE on this kernel's own streams (MI355X_MICROARCH.md: widths other than
 # 16 B/lane are uncalibrated): (a) isolated-vertex bucket alone = 16 B/lane streaming reads of a
 # known size; (b) XS tiles alone with every gather folded into 1 KiB = the 4 B/lane entry stream
+# the masks / profile stamps exist only in the timing-aid build (make -C cugraph_amd/csrc AIDS=1)
+export CUGRAPH_AMD_LIBRARY=${CUGRAPH_AMD_LIBRARY:-/root/repo/cugraph_amd/libcugraph_amd_c_aids.so}
 B="bench.py --scale 26 --steps 5 --warmup 2 --no-cpu-baseline --no-convergence"
 export TMPDIR=/tmp
 CUGRAPH_AMD_BUCKET_MASK=16 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_cal_iso -- python3 $B > /dev/null 2>&1 || echo a-fail
