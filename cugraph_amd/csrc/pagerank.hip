@@ -1815,7 +1815,10 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   char const* pm_env = std::getenv("CUGRAPH_AMD_XS_PHASE_MIN");
   int const part_windows  = pw_env ? std::atoi(pw_env) : 3;
   int64_t const phase_min = pm_env ? std::atoll(pm_env) : (int64_t(1) << 18);  // entries per unit
-  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows) ? (n_win + part_windows - 1) / part_windows : 1;
+  // (only for 16384-row tiles, the layout the parts were measured and run at full size with: graphs
+  // whose source space needs 4096- or 8192-row tiles keep whole-unit items)
+  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows && row_bits == kXsRowBitsMax)
+                        ? (n_win + part_windows - 1) / part_windows : 1;
   std::vector<XsItem> h_items[2];
   std::vector<std::vector<XsItem>> part_items(n_parts);  // region 0 of phased tiles, by part
   std::vector<int64_t> h_fin;
