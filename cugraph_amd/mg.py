@@ -330,6 +330,10 @@ class MGPagerank:
         # [0, P*C0) and of the rest [P*C0, P*C0 + P*C1); None: one region of P chunks
         self.regions = None
         self.out_w = None  # out-weight sums of the local vertices (float64), internal order
+        # personalised exchange (CUGRAPH_AMD_MG_EXCHANGE=personal): own sources, foreign sources read,
+        # per-rank split sizes of the all-to-all and the indices (among the own sources) to pack
+        self.n_own = self.n_foreign = 0
+        self.want_split = self.give_split = self.idx_give = None
         self.value_dtype = None
         self.vertex_dtype = None
         self.t_generate = 0.0
@@ -395,7 +399,35 @@ class MGPagerank:
             slot_of = all_gather_ragged(mine, self.lengths, rank, world, group, fill=-1)
             return x_pos, slot_of, n_slots, hot_slots
 
-        x_pos, slot_of, n_slots, hot_slots = assign_slots()
+        def assign_private_slots():
+            """The PERSONALISED exchange (CUGRAPH_AMD_MG_EXCHANGE=personal): a slot numbering of this
+            rank's own -- its sources first, in row order, then one block per other rank holding
+            exactly the sources of that rank which this rank's edges read, in that rank's row
+            order.  Returns x_pos, the slot of every local edge's source, the number of own sources
+            and the sorted (owner << 32 | index among the owner's sources) keys of the foreign ones."""
+            order = self.order.long()
+            active = own_counts[order] > 0
+            n_own = int(torch.count_nonzero(active))
+            j = torch.cumsum(active, 0) - 1
+            x_pos = torch.where(active, j, torch.full_like(order, -1)).to(torch.int32)
+            mine = torch.full((self.last - self.first,), -1, dtype=torch.int32, device=src.device)
+            mine[order] = x_pos
+            index_at_owner = all_gather_ragged(mine, self.lengths, rank, world, group, fill=-1)
+            inner = torch.as_tensor(self.bounds[1:-1], dtype=torch.int64, device=src.device)
+            owner = torch.bucketize(src.to(torch.int64), inner, right=True)
+            j_src = index_at_owner[src.long()].long()
+            key = (owner << 32) + j_src
+            foreign = owner != rank
+            uniq = torch.unique(key[foreign])  # ascending: owner-major, then the owner's row order
+            pos = torch.searchsorted(uniq, key) if uniq.numel() else torch.zeros_like(key)
+            slot = torch.where(foreign, n_own + pos, j_src)
+            return x_pos, slot, n_own, uniq
+
+        personal = world > 1 and os.environ.get("CUGRAPH_AMD_MG_EXCHANGE") == "personal"
+        if personal:
+            x_pos, src_slot, n_own, uniq = assign_private_slots()
+        else:
+            x_pos, slot_of, n_slots, hot_slots = assign_slots()
         # rows of in-degree 1-3 in the order of their smallest source (decided for all ranks alike:
         # the slots are assigned again afterwards, which is a collective)
         n_edges_all = torch.tensor([src.numel()], dtype=torch.int64, device=src.device)
@@ -404,13 +436,33 @@ class MGPagerank:
         env = os.environ.get("CUGRAPH_AMD_RENUMBER_LOCALITY")
         if env == "1" or (env is None and int(n_edges_all.item()) >= (1 << 22)):
             rows = self.rank_local[(dst - self.first).long()].long()
-            self._order_low_degree_rows_by_source(slot_of[src.long()].long(), rows)
-            del rows, x_pos, slot_of
+            self._order_low_degree_rows_by_source(src_slot if personal else slot_of[src.long()].long(), rows)
+            del rows, x_pos
             # slots follow the rows, so that a rank still writes its values in row order
-            x_pos, slot_of, n_slots, hot_slots = assign_slots()
-        src = slot_of[src.long()].to(self.vertex_dtype)
+            if personal:
+                x_pos, src_slot, n_own, uniq = assign_private_slots()
+            else:
+                del slot_of
+                x_pos, slot_of, n_slots, hot_slots = assign_slots()
+        if personal:
+            # every owner learns which of its sources each rank reads (counts, then the index lists)
+            want = torch.bincount(uniq >> 32, minlength=world)
+            give = torch.empty_like(want)
+            all_to_all_single(give, want, group=group)
+            self.want_split = [int(c) for c in want.tolist()]
+            self.give_split = [int(c) for c in give.tolist()]
+            self.idx_give = torch.empty(sum(self.give_split), dtype=torch.int64, device=src.device)
+            all_to_all_single(self.idx_give, (uniq & 0xFFFFFFFF).contiguous(), self.give_split, self.want_split, group)
+            self.n_own, self.n_foreign = n_own, int(uniq.numel())
+            n_slots, hot_slots = max(n_own + self.n_foreign, 1), 0
+            self.regions, self.slot_chunk = None, 0
+            engine.private_slots = True  # (the CPU stand-in checks the chunk layout otherwise)
+            src = src_slot.to(self.vertex_dtype)
+            del src_slot, uniq
+        else:
+            src = slot_of[src.long()].to(self.vertex_dtype)
+            del slot_of
         dst = (self.rank_local[(dst - self.first).long()] + self.first).to(self.vertex_dtype)
-        del slot_of
         order = self.order.long()
         self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last, self.num_vertices,
                                              num_source_slots=n_slots, x_pos=x_pos, hot_slots=hot_slots)
@@ -624,6 +676,13 @@ class MGPagerank:
         total = scal[2:4].clone()
         all_reduce(total, self.group)
         scal[0:2].copy_(total)
+        if self.idx_give is not None:
+            # personalised exchange: every rank packs, per reader, the values that reader's edges
+            # gather (one index list) and one all-to-all lands them in the readers' blocks
+            packed = x_full[:self.n_own].index_select(0, self.idx_give)
+            all_to_all_single(x_full[self.n_own:self.n_own + self.n_foreign], packed, self.want_split,
+                              self.give_split, self.group)
+            return ()
         if self.regions is None:
             return (all_gather_region_async(x_full[:self.slot_chunk * self.world], self.slot_chunk, self.rank,
                                             self.world, self.group),)

@@ -11,7 +11,9 @@ import torch
 
 
 class _Graph:
-    def __init__(self, src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots=0):
+    def __init__(self, src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots=0,
+                 private_slots=False):
+        self.private_slots = private_slots  # personalised exchange: a slot numbering of this rank's own
         self.first, self.last, self.num_global = first, last, num_global
         self.slots = num_source_slots
         self.hot_slots = hot_slots  # slots below it: the first region of the gathered vector
@@ -27,17 +29,12 @@ class _Session:
                  pers_v=None, pers_x=None):
         self.g, self.alpha, self.eps = g, alpha, epsilon
         nl = g.last - g.first
-        assert g.slots % world == 0 and np.all(g.src < g.slots)
+        assert np.all(g.src < g.slots)
         mine = g.x_pos[g.x_pos >= 0]
-        # this rank writes only its own sub-chunk of each region (one region: P equal chunks)
-        assert g.hot_slots % world == 0 and (g.slots - g.hot_slots) % world == 0
-        c0, c1 = g.hot_slots // world, (g.slots - g.hot_slots) // world
-        hot = mine[mine < g.hot_slots]
-        rest = mine[mine >= g.hot_slots] - g.hot_slots
-        assert np.all((hot >= rank * c0) & (hot < (rank + 1) * c0))
-        assert np.all((rest >= rank * c1) & (rest < (rank + 1) * c1))
-        if g.hot_slots:
-            assert len(hot) == min(c0, len(mine))  # the hot region takes a rank's first (hottest) sources
+        if g.private_slots:  # own sources first, in row order
+            assert np.array_equal(mine, np.arange(len(mine)))
+        else:
+            self._check_chunks(g, world, rank, mine)
         self.wr = g.x_pos >= 0
         self.out_w = np.zeros(nl)
         self.out_w[out_w_v.numpy() - g.first] = out_w.numpy()
@@ -58,6 +55,19 @@ class _Session:
         self.x[0][g.x_pos[self.wr]] = torch.from_numpy(xs[self.wr])
         self.scal[0] = self.scal[2] = float(self.pr[dang].sum())
         self.scal[1] = self.scal[3] = 1e300
+
+    @staticmethod
+    def _check_chunks(g, world, rank, mine):
+        # this rank writes only its own sub-chunk of each region (one region: P equal chunks)
+        assert g.slots % world == 0
+        assert g.hot_slots % world == 0 and (g.slots - g.hot_slots) % world == 0
+        c0, c1 = g.hot_slots // world, (g.slots - g.hot_slots) // world
+        hot = mine[mine < g.hot_slots]
+        rest = mine[mine >= g.hot_slots] - g.hot_slots
+        assert np.all((hot >= rank * c0) & (hot < (rank + 1) * c0))
+        assert np.all((rest >= rank * c1) & (rest < (rank + 1) * c1))
+        if g.hot_slots:
+            assert len(hot) == min(c0, len(mine))  # the hot region takes a rank's first (hottest) sources
 
     def iterate(self, n=1):
         g = self.g
@@ -117,7 +127,8 @@ class OracleEngine:
 
     def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
                          x_pos=None, hot_slots=0):
-        return _Graph(src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots)
+        return _Graph(src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots,
+                      getattr(self, "private_slots", False))
 
     def window_slots(self, num_source_slots):
         # small enough for the test graphs to get two regions (the library's are 2^21..2^23 slots)

@@ -36,6 +36,7 @@ def _worker(rank, world, port, case, out_dir):
     # rows of in-degree 1-3 in the order of their smallest source slot (default: big graphs only)
     os.environ["CUGRAPH_AMD_RENUMBER_LOCALITY"] = case.get("locality", "0")
     os.environ["CUGRAPH_AMD_MG_PARTITION"] = case.get("partition", "edges")
+    os.environ["CUGRAPH_AMD_MG_EXCHANGE"] = case.get("exchange", "gather")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         src, dst, wgt, nv = case["src"], case["dst"], case["wgt"], case["nv"]
@@ -53,6 +54,13 @@ def _worker(rank, world, port, case, out_dir):
             assert (first, last) == mg.partition_bounds(nv, world, rank)[:2]
         if "want_regions" in case:
             assert (drv.regions is not None) == case["want_regions"]
+        if case.get("exchange") == "personal":
+            # a slot numbering of this rank's own: its sources, then exactly the foreign sources its edges read
+            assert drv.idx_give is not None and drv.regions is None
+            assert drv.graph.slots == max(drv.n_own + drv.n_foreign, 1)
+            used = np.unique(drv.graph.src)
+            assert np.array_equal(used[used >= drv.n_own], np.arange(drv.n_own, drv.n_own + drv.n_foreign))
+            assert sum(drv.want_split) == drv.n_foreign and drv.want_split[rank] == 0 and drv.give_split[rank] == 0
         assert drv.graph.first == first and len(drv.out_w) == last - first
         nstart, pers = case.get("nstart"), case.get("pers")
         if case.get("sharded"):
@@ -133,6 +141,27 @@ def test_mg_matches_single_process_oracle(world, regions, want_regions, weighted
         assert bool(m[2]) and bool(m[3]) == o_conv
         assert np.max(np.abs(f - o_pr)) < 1e-12
     assert abs(fulls[0].sum() - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("world,locality", [(2, "0"), (3, "1"), (5, "1")])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_mg_personalised_exchange(world, locality, weighted, tmp_path):
+    """CUGRAPH_AMD_MG_EXCHANGE=personal: every rank numbers its slots privately (own sources, then
+    per owner exactly the sources its edges read) and the per-iteration exchange is one all-to-all
+    of what each reader gathers instead of an all-gather of everything: same ranks, same iteration
+    count, personalization and an initial guess included."""
+    rng = np.random.default_rng(3)
+    nv = 1 << 9
+    pers = (rng.permutation(nv)[:23].astype(np.int64), rng.random(23) + 0.1)
+    nstart = (rng.permutation(nv)[:200].astype(np.int64), rng.random(200))
+    case = _rmat_case(9, weighted, exchange="personal", locality=locality, pers=pers, nstart=nstart,
+                      eps=1e-12, check=4)
+    fulls, metas = _run(world, case, tmp_path)
+    o_pr, o_it, o_conv = _oracle(case)
+    for f, m in zip(fulls, metas):
+        assert m[0] == o_it and m[1] == o_it and bool(m[2]) and bool(m[3]) == o_conv
+        # (an unweighted graph takes its personalization and initial guess as fp32 at the API)
+        assert np.max(np.abs(f - o_pr)) < (1e-12 if weighted else 1e-8)
 
 
 @pytest.mark.parametrize("sharded", [False, True])
