@@ -444,6 +444,17 @@ def main():
         "iteration_ms_event_avg": float(iter_ms.mean()),
     }
 
+    # a timing-aid build (make AIDS=1, CUGRAPH_AMD_LIBRARY) checks every address xs_kernel computes
+    # against its arrays and records violations instead of faulting: say what it saw
+    from cugraph_amd import _capi as _capi_mod
+    _lib = _capi_mod.load()
+    if hasattr(_lib, "cugraph_amd_aids_bounds_check"):
+        import ctypes
+        chk = (ctypes.c_ulonglong * 8)()
+        _lib.cugraph_amd_aids_bounds_check(chk)
+        print("xs_kernel bounds check: violations %d first{kind %d v0 %d v1 %d workgroup %d tile %d slice %d}"
+              % (chk[0], chk[1], chk[2], chk[3], chk[4], chk[5] & 0xffffffff, chk[5] >> 32), file=sys.stderr)
+
     # ---------------- time to convergence at NetworkX tol = 1e-8 (epsilon = N * tol)
     conv = conv_abs = None
     if not args.no_convergence:

@@ -1131,6 +1131,18 @@ int cugraph_amd_aids_region_check(unsigned long long out[2])
     return 1;
   }
 }
+// out[0] = accesses of xs_kernel outside its arrays so far (recorded and redirected instead of
+// faulting), out[1..5] = kind (1 entry stream, 2 gather, 3 partials), two values, workgroup and
+// tile | slice << 32 of the first one
+int cugraph_amd_aids_bounds_check(unsigned long long out[8])
+{
+  try {
+    cga::xs_bounds_check_read(out);
+    return 0;
+  } catch (...) {
+    return 1;
+  }
+}
 #endif
 
 }  // extern "C"

@@ -279,6 +279,7 @@ CompressedOut compress_coo_perm(hipStream_t stream, int64_t n_major, int64_t n_m
                                 bool ties_in_input_order = true);
 #ifdef CGA_TIMING_AIDS
 void xs_region_check_read(unsigned long long* out);  // pagerank.hip, timing-aid build only
+void xs_bounds_check_read(unsigned long long* out);  // pagerank.hip, timing-aid build only
 #endif
 CompressedOut compress_coo_keys(hipStream_t stream, int64_t n_major, int64_t n_edges, int32_t const* majors,
                                 uint32_t const* keys, int sort_from_bit, int sort_to_bit);

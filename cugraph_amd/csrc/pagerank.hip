@@ -54,6 +54,12 @@ constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longe
 constexpr int kXsRowBits      = 12;
 constexpr int kXsRowBitsMax   = 14;
 constexpr int kXsMinDegree    = kLowDegreeMax + 1;
+#ifdef CGA_XS_NO_DENSE
+constexpr bool kXsDense = false;
+#else
+constexpr bool kXsDense = true;  // dense passes of xs_kernel: one coalesced load + cross-lane reads
+#endif
+constexpr bool kXsWideDefault = false;  // two 1024-thread workgroups per CU on 8192-row tiles (build_xs)
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
 // a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile
@@ -98,7 +104,13 @@ struct XsArgs {
   int profile;           // per-workgroup times into xs_prof_buf
   uint32_t gather_mask;  // narrows every gathered index (results are then wrong)
   int no_atomics;        // row sums are not accumulated (one add per lane and pass keeps the loads alive)
+  int no_gather;         // nothing is gathered (every source value reads as 1)
+  int no_writeback;      // the partials are not stored (the accumulators are still cleared)
   uint32_t slot_limit;   // region 0 of a partitioned graph: gathers at or beyond it are counted (0: no check)
+  // bounds of the three arrays xs_kernel addresses with computed indices: an access outside them is
+  // recorded in xs_check_buf (and redirected) instead of faulting the GPU
+  int64_t ent_len, partial_len;
+  uint32_t x_len;
 #endif
 };
 
@@ -539,11 +551,48 @@ __device__ unsigned long long xs_prof_buf[1024 * 8];
 // be running then: there must be none), and the region-0 launches checked
 __device__ unsigned long long xs_region_check[2];
 #define CGA_XSP(stmt) do { if (a.xs.profile) { stmt; } } while (0)
+// bounds checks of xs_kernel's computed addresses: [0] violations, [1] kind of the first (1 entry
+// stream, 2 gather, 3 partials), [2..3] two values of it, [4] its workgroup, [5] tile | slice << 32
+__device__ unsigned long long xs_check_buf[8];
+#define CGA_XS_CHECK(cond, kind, v0, v1)                                                            \
+  do {                                                                                              \
+    if (cond) {                                                                                     \
+      if (atomicAdd(&xs_check_buf[0], 1ull) == 0ull) {                                              \
+        xs_check_buf[1] = (kind);                                                                   \
+        xs_check_buf[2] = static_cast<unsigned long long>(v0);                                      \
+        xs_check_buf[3] = static_cast<unsigned long long>(v1);                                      \
+        xs_check_buf[4] = blockIdx.x;                                                               \
+        xs_check_buf[5] = static_cast<unsigned long long>(t) | (static_cast<unsigned long long>(k) << 32); \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
 #else
 #define CGA_XSP(stmt) do { } while (0)
+#define CGA_XS_CHECK(cond, kind, v0, v1) do { } while (0)
 #endif
 
 typedef double v2f64_t __attribute__((ext_vector_type(2)));
+
+// (make VARIANT=phase EXTRA=-DCGA_XS_PHASE_PROF) where a wave's time goes inside its passes: shader
+// clock ticks summed over all waves of a launch -- [0] passes, [1] claim + window tracking,
+// [2] address arithmetic + issue of gathers and next entries, [3] wait for the gathers, [4] LDS
+// accumulation (to completion), [5] item boundaries (end of last pass -> first pass of next item),
+// [6] whole kernel, [7] fast passes
+#ifdef CGA_XS_PHASE_PROF
+__device__ unsigned long long xs_phase_buf[8];
+__global__ void xs_phase_dump_kernel()
+{
+  printf("XSPHASE passes %llu fast %llu | per wave-pass ticks: claim+windows %.0f issue %.0f gather-wait %.0f accumulate %.0f | "
+         "boundaries total %llu kernel total %llu (sums over waves) pass-sum %llu\n",
+         xs_phase_buf[0], xs_phase_buf[7], (double)xs_phase_buf[1] / xs_phase_buf[0], (double)xs_phase_buf[2] / xs_phase_buf[0],
+         (double)xs_phase_buf[3] / xs_phase_buf[0], (double)xs_phase_buf[4] / xs_phase_buf[0], xs_phase_buf[5], xs_phase_buf[6],
+         xs_phase_buf[1] + xs_phase_buf[2] + xs_phase_buf[3] + xs_phase_buf[4]);
+  for (int i = 0; i < 8; ++i) xs_phase_buf[i] = 0;
+}
+#define CGA_PH(stmt) do { stmt; } while (0)
+#else
+#define CGA_PH(stmt) do { } while (0)
+#endif
 
 // wait for this wave's LDS operations, then the workgroup barrier: unlike __syncthreads() it does
 // not wait for the wave's global stores (the partials just written need not have landed)
@@ -562,8 +611,12 @@ __device__ inline void lds_barrier()
 // 39 % of the kernel (profiles/r2_xs_waves.md).  With claims all waves reach the end of an item
 // within one wave pass of each other.  Each wave software-pipelines its own passes: the entries
 // of its next pass are requested right after the gathers of the current one were issued.
-template <typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EPL>
-__global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
+// WPE: waves per SIMD the register allocation is held to (__launch_bounds__'s second argument):
+// 8 = 64 VGPRs, so that two 1024-thread workgroups are resident on a CU (8192-row tiles: 2 x 65 KiB
+// of LDS) and the item boundaries of one -- drain, write-back, re-fill: ~13 us, 23 % of wave 0's
+// time with one workgroup per CU (profiles/r2_xs_waves.md) -- are covered by the passes of the other.
+template <typename ValT, bool WEIGHTED, int THREADS, int ROWBITS, int EPL, int WPE>
+__global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
 {
   constexpr int kLowBits       = 32 - ROWBITS;
   constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
@@ -586,6 +639,11 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
   unsigned long long const pt_t0 = wall_clock64();
 #else
   int const my = static_cast<int>(xcc_id() & (kXsSlices - 1));
+#endif
+#ifdef CGA_XS_PHASE_PROF
+  unsigned long long ph_n = 0, ph_claim = 0, ph_issue = 0, ph_wait = 0, ph_acc = 0, ph_bound = 0, ph_fast = 0;
+  unsigned long long const ph_k0 = clock64();
+  unsigned long long ph_t = ph_k0, ph_end = ph_k0;
 #endif
   // the accumulators start at zero and every write-back leaves them at zero
   for (int i = tid; i < (1 << ROWBITS); i += THREADS) acc[i] = 0.0;
@@ -612,7 +670,10 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
     uint32_t const kbits = static_cast<uint32_t>(k) << shift;
     // the first item of a queue is fetched on the spot, every later one during the item before it
     // (not further ahead: an item reserved by a busy workgroup is an item an idle one cannot take,
-    // and a small graph has only a few items per workgroup)
+    // and a small graph has only a few items per workgroup).  It goes to the buffer nobody reads:
+    // the terminal record of the previous queue sits in the current one, and a wave that lags
+    // behind wave 0 may not have looked at it yet (no barrier separates that read from this write).
+    buf ^= 1;
     if (wave0) {
       int q = 0;
       if (lane == 0) q = atomicAdd(&xs.counters[k], 1);
@@ -631,10 +692,9 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
       uint32_t const n_pc  = static_cast<uint32_t>(head >> 40) & 0xffu;
       int const rows    = static_cast<int>(uniform64(rec[1]) >> 32);
       ValT* const out   = xs.partial + uniform64(rec[2]);
-      // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise,
-      // so every lane keeps the 4 row sums in registers and the block reduces them at the end
+      // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise, so
+      // every lane adds into LDS words of its own and wave 0 folds them at the end of the item
       bool const few = rows <= 4;
-      double racc[4] = {0.0, 0.0, 0.0, 0.0};
       // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
       // from its position.  bound(w): first position of window w relative to the aligned start
       // (0 for a window that starts before this item's entries -- an item can be the tail of a
@@ -657,7 +717,9 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
       uint32_t const n_pass = (rend + kPass - 1) / kPass;
       uint32_t const pb_lo  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * piece / n_pc) * kPass;
       uint32_t const pb_hi  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * (piece + 1) / n_pc) * kPass;
-      uint32_t const n_wp   = (pb_hi - pb_lo) / kWavePass;
+      // (a piece's share is whole workgroup passes; the wave passes past the unit's end are not run)
+      uint32_t const pb_end = pb_hi < rend ? pb_hi : rend;
+      uint32_t const n_wp   = pb_end > pb_lo ? (pb_end - pb_lo + kWavePass - 1) / kWavePass : 0u;
       // window of the piece's first entry: the last one that starts at or before it (the starts
       // ascend; empty windows share a start with their successor).  A wave's passes ascend, so
       // its window only ever moves forward from here.
@@ -677,14 +739,27 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
       uint32_t const q_last = (rend > 0 ? rend : 1u) - 1u;
       uint32_t en[EPL];
       ValT w[EPL];
+      // The pass's first entry is a wave-uniform address; a lane adds a small offset of its own
+      // (scalar base + 32-bit lane offset: no 64-bit address arithmetic per load, no address pairs
+      // in vector registers).
       auto fetch = [&](uint32_t pb, uint32_t* en_out, ValT* w_out) {
-        uint32_t const pos = pb + static_cast<uint32_t>(lane);
+        uint32_t const pbc = pb < q_last ? pb : q_last;
+        uint32_t lim       = q_last - pbc;
+        int64_t first      = abeg + static_cast<int64_t>(pbc);
+#ifdef CGA_TIMING_AIDS
+        if (first < 0 || first + lim >= xs.ent_len) {
+          CGA_XS_CHECK(true, 1, first, lim);
+          first = 0;
+          lim   = 0u;
+        }
+#endif
+        uint32_t const* const eb = xs.ent + first;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          uint32_t q = pos + e * 64;
-          q          = q < q_last ? q : q_last;
-          en_out[e]  = __builtin_nontemporal_load(xs.ent + abeg + q);
-          if constexpr (WEIGHTED) w_out[e] = __builtin_nontemporal_load(xs.w + abeg + q);
+          uint32_t q = static_cast<uint32_t>(lane) + e * 64;
+          q          = q < lim ? q : lim;
+          en_out[e]  = __builtin_nontemporal_load(eb + q);
+          if constexpr (WEIGHTED) w_out[e] = __builtin_nontemporal_load(xs.w + first + q);
         }
       };
       // FAST: all entries of the pass exist and lie in one window (decided on uniform values)
@@ -708,35 +783,130 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
           }
         }
         ValT xv[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          uint32_t const loc = (wn[e] << kLowBits) | (en[e] >> ROWBITS);  // slice-local source position
-          uint32_t gi        = ((loc & ~low_mask) << 3) | kbits | (loc & low_mask);
-          // an entry that is not the item's was clamped to the item's last one, but its window was
-          // counted from its own position: the slot may not exist.  Slot 0 always does.
-          if constexpr (!FAST) gi = p[e] ? gi : 0u;
+        // The gathers of one window: its first slot (of this slice) is a wave-uniform address, an
+        // entry's own bits a 32-bit offset from it (below 2^(35 - ROWBITS) elements) -- scalar base
+        // + lane offset again.  A pass that crosses window starts gathers window by window, every
+        // lane that has no entry in the window re-reading the window's first slot (which exists:
+        // the window holds an entry of this unit); such passes are few.
+        auto gather1 = [&](uint32_t wi, uint32_t off) -> ValT {
 #ifdef CGA_TIMING_AIDS
+          if (xs.no_gather) return ValT(1);
+          uint32_t gi = ((wi << (kLowBits + 3)) | kbits) + off;
           if (a.xs.slot_limit != 0u && gi >= a.xs.slot_limit) atomicAdd(&xs_region_check[0], 1ull);
+          if (gi >= xs.x_len) {
+            CGA_XS_CHECK(true, 2, gi, (static_cast<uint64_t>(wi) << 32) | off);
+            gi = 0u;
+          }
+          return a.x_cur[CGA_GMASK(a.xs, gi)];
+#else
+          [[maybe_unused]] ValT const* const xb = a.x_cur + ((static_cast<uint64_t>(wi) << (kLowBits + 3)) | kbits);
+#if defined(CGA_XS_GATHER_SC1)
+          return __hip_atomic_load(xb + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif defined(CGA_XS_ABL_NOGATHER)
+          return ValT(1) + static_cast<ValT>(off & 1u);
+#elif defined(CGA_XS_ABL_MASK)
+          return xb[off & CGA_XS_ABL_MASK];
+#else
+          return xb[off];
 #endif
-          xv[e] = a.x_cur[CGA_GMASK(a.xs, gi)];
+#endif
+        };
+        // DENSE passes.  The entries of a unit ascend by source, so the 512 entries of a pass over a
+        // hot stretch of the source space (a hub tile's hot window: tens of entries per source)
+        // name only a few dozen consecutive source positions -- and as eight gather instructions
+        // they hit the same one or two cache lines eight times, most of them while the line is
+        // still on its way from L2: the L1 stalls on every such hit (TCP_PENDING_STALL_CYCLES: 63 %
+        // of xs_kernel's cycles, profiles/r3_xs_diag.md; why neither more waves nor more loads in
+        // flight made the kernel faster).  When the pass spans fewer than 64 (128) positions the wave
+        // loads that stretch of x ONCE, lane l taking position first + l (one or two coalesced
+        // loads), and every entry takes its value from the lane that holds it (ds_bpermute: the
+        // LDS crossbar, no memory access).
+        int dense = 0;
+        ValT xd0 = ValT(0), xd1 = ValT(0);
+        uint32_t s_first = 0u;
+        if constexpr (FAST) {
+          uint32_t const s_last = __builtin_amdgcn_readlane(en[EPL - 1] >> ROWBITS, 63);
+          s_first               = __builtin_amdgcn_readfirstlane(en[0] >> ROWBITS);
+          uint32_t const span   = s_last - s_first;
+          dense                 = kXsDense ? (span < 64u ? 1 : span < 128u ? 2 : 0) : 0;
+          if (dense) {
+            // (positions up to the pass's last one exist; the lanes beyond it re-read that one)
+            uint32_t p0 = s_first + static_cast<uint32_t>(lane);
+            p0          = p0 < s_last ? p0 : s_last;
+            xd0         = gather1(static_cast<uint32_t>(w_lo), ((p0 & ~low_mask) << 3) | (p0 & low_mask));
+            if (dense == 2) {
+              uint32_t p1 = s_first + 64u + static_cast<uint32_t>(lane);
+              p1          = p1 < s_last ? p1 : s_last;
+              xd1         = gather1(static_cast<uint32_t>(w_lo), ((p1 & ~low_mask) << 3) | (p1 & low_mask));
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              uint32_t const lo = en[e] >> ROWBITS;
+              xv[e]             = gather1(static_cast<uint32_t>(w_lo), ((lo & ~low_mask) << 3) | (lo & low_mask));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) xv[e] = ValT(0);
+          for (int wi = w_lo; wi <= w_hi; ++wi) {
+            if (bound(wi + 1) <= bound(wi)) continue;  // no entry of this item in window wi
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              uint32_t const lo = en[e] >> ROWBITS;
+              // (an entry that is not the item's was clamped to the item's last one: dropped)
+              bool const mine   = p[e] && wn[e] == static_cast<uint32_t>(wi);
+              ValT const v      = gather1(static_cast<uint32_t>(wi), mine ? ((lo & ~low_mask) << 3) | (lo & low_mask) : 0u);
+              xv[e]             = mine ? v : xv[e];
+            }
+          }
         }
         uint32_t en_next[EPL];
         ValT w_next[EPL];
         if (have_next) fetch(pb_next, en_next, w_next);
+        CGA_PH(unsigned long long const t2 = clock64(); ph_issue += t2 - ph_t; ph_t = t2);
+        if constexpr (FAST) {
+          if (dense == 1) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) xv[e] = __shfl(xd0, static_cast<int>((en[e] >> ROWBITS) - s_first), 64);
+          } else if (dense == 2) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              uint32_t const d = (en[e] >> ROWBITS) - s_first;
+              ValT const v0    = __shfl(xd0, static_cast<int>(d & 63u), 64);
+              ValT const v1    = __shfl(xd1, static_cast<int>(d & 63u), 64);
+              xv[e]            = d < 64u ? v0 : v1;
+            }
+          }
+        }
         if constexpr (WEIGHTED) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
         }
+#ifdef CGA_XS_PHASE_PROF
+        {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) asm volatile("" : "+v"(xv[e]));
+          unsigned long long const t3 = clock64();
+          ph_wait += t3 - ph_t;
+          ph_t = t3;
+        }
+#endif
         if (few) {
+          // every lane adds into words of its own: 64 accumulators per row behind the (at most 4)
+          // row sums, folded after the item's passes
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            double v    = p[e] ? static_cast<double>(xv[e]) : 0.0;
-            uint32_t rl = en[e] & kRowMask;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) racc[rr] += rl == (uint32_t)rr ? v : 0.0;
-          }
+          for (int e = 0; e < EPL; ++e)
+            if (p[e]) atomicAdd(&acc[4 + ((en[e] & 3u) << 6) + lane], static_cast<double>(xv[e]));
 #ifdef CGA_TIMING_AIDS
         } else if (xs.no_atomics) {
+          ValT sum = 0;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
+          if (sum == ValT(-1)) atomicAdd(&acc[0], 1.0);
+#endif
+#if defined(CGA_XS_ABL_NOATOM)
+        } else if (true) {
           ValT sum = 0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
@@ -747,6 +917,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
           for (int e = 0; e < EPL; ++e)
             if (p[e]) atomicAdd(&acc[en[e] & kRowMask], static_cast<double>(xv[e]));
         }
+        CGA_PH(unsigned long long const t4 = clock64(); ph_acc += t4 - ph_t; ph_t = t4; ph_n += 1; ph_fast += FAST ? 1 : 0);
         if (have_next) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
@@ -763,6 +934,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
       if (wave0 && lane == 0) q_next = atomicAdd(&xs.counters[k], 1);
       uint32_t i0 = claim(), i1 = claim();
       if (i0 < n_wp) fetch(pb_lo + i0 * kWavePass, en, w);
+      CGA_PH(unsigned long long const tb = clock64(); ph_bound += tb - ph_end; ph_t = tb);
       while (i0 < n_wp) {
         uint32_t const pb = pb_lo + i0 * kWavePass, pe = pb + kWavePass;
         uint32_t const i2 = claim();
@@ -773,6 +945,7 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
         }
         bool const have_next = i1 < n_wp;
         uint32_t const pb_next = pb_lo + i1 * kWavePass;
+        CGA_PH(unsigned long long const t1 = clock64(); ph_claim += t1 - ph_t; ph_t = t1);
         if (pb >= rbeg && pe <= rend && pe <= nb) {
           pass(std::true_type{}, pb, pb_next, have_next, w_cur, w_cur);
         } else {
@@ -790,38 +963,70 @@ __global__ __launch_bounds__(THREADS) void xs_kernel(XsLaunch<ValT> a)
         }
         i0 = i1;
         i1 = i2;
+        CGA_PH(ph_t = clock64());
       }
+      CGA_PH(ph_end = clock64());
       if (wave0 && !rec_asked) r_next = load_record(k, __shfl(q_next, 0));
       CGA_XSP(pt_a = wall_clock64());
-      if (few) {
+      __syncthreads();
+      if (few && wave0) {
+        // (thread 0 writes rows 0..3 back: the same wave, so its LDS reads follow these writes)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          double v = group_sum(racc[rr], 64);
-          if (lane == 0 && rr < rows) atomicAdd(&acc[rr], v);
+          double v               = acc[4 + (rr << 6) + lane];
+          acc[4 + (rr << 6) + lane] = 0.0;
+          v                      = group_sum(v, 64);
+          if (lane == 0) acc[rr] = v;
         }
       }
-      __syncthreads();
       CGA_XSP(pt_c = wall_clock64(); pt_b1 += pt_c - pt_a);
       // the partials of a tile are padded to a multiple of 4 rows (build_xs): whole vectors
       int const rows4 = (rows + 3) & ~3;
-      for (int i = tid * 4; i < rows4; i += THREADS * 4) {
+      // (the thread's index made opaque here: what is derived from it -- LDS and partial addresses,
+      // loop-invariant for the compiler -- would otherwise be kept in registers, or spilled, across
+      // the passes of every item)
+      int tw = tid;
+      asm volatile("" : "+v"(tw));
+      for (int i = tw * 4; i < rows4; i += THREADS * 4) {
         v2f64_t const s0 = *reinterpret_cast<v2f64_t const*>(acc + i);
         v2f64_t const s1 = *reinterpret_cast<v2f64_t const*>(acc + i + 2);
         ValT const r4[4] = {static_cast<ValT>(s0.x), static_cast<ValT>(s0.y), static_cast<ValT>(s1.x),
                             static_cast<ValT>(s1.y)};
+#ifdef CGA_TIMING_AIDS
+        if ((out - xs.partial) + i < 0 || (out - xs.partial) + i + 4 > xs.partial_len) {
+          CGA_XS_CHECK(true, 3, out - xs.partial, i);
+        } else if (xs.no_writeback) {
+        } else
+#endif
         stream_store_vals4(out + i, r4);
         v2f64_t const z = {0.0, 0.0};
         *reinterpret_cast<v2f64_t*>(acc + i)     = z;
         *reinterpret_cast<v2f64_t*>(acc + i + 2) = z;
       }
       CGA_XSP(pt_wbk += wall_clock64() - pt_c);
-      if (wave0 && lane < kXsRecWords) s_rec[buf ^ 1][lane] = r_next;
+      if (wave0) {
+        int lw = lane;
+        asm volatile("" : "+v"(lw));
+        if (lw < kXsRecWords) s_rec[buf ^ 1][lw] = r_next;
+      }
       if (tid == 0) s_claim = 0;
       buf ^= 1;
       lds_barrier();
       CGA_XSP(pt_bound += wall_clock64() - pt_a);
     }
   }
+#ifdef CGA_XS_PHASE_PROF
+  if (lane == 0) {
+    atomicAdd(&xs_phase_buf[0], ph_n);
+    atomicAdd(&xs_phase_buf[1], ph_claim);
+    atomicAdd(&xs_phase_buf[2], ph_issue);
+    atomicAdd(&xs_phase_buf[3], ph_wait);
+    atomicAdd(&xs_phase_buf[4], ph_acc);
+    atomicAdd(&xs_phase_buf[5], ph_bound);
+    atomicAdd(&xs_phase_buf[6], clock64() - ph_k0);
+    atomicAdd(&xs_phase_buf[7], ph_fast);
+  }
+#endif
 #ifdef CGA_TIMING_AIDS
   if (xs.profile && tid == 0 && blockIdx.x < 1024) {
     unsigned long long* o8 = xs_prof_buf + 8 * blockIdx.x;
@@ -851,21 +1056,30 @@ struct XsKernelChoice {
   int lds;
 };
 
-constexpr int xs_threads_for(int row_bits) { return kThreads << (row_bits - kXsRowBits); }
+// Threads of a workgroup: 4096 threads per CU whatever the tile (256 x 4, 512 x 2, 1024 x 1) -- or,
+// `wide`, two 1024-thread workgroups on 8192-row tiles (8 waves per SIMD, 64 VGPRs a lane), which
+// the unweighted fp32 / fp64 kernels fit into without spilling.
+constexpr int xs_threads_for(int row_bits, bool wide = false)
+{
+  return wide && row_bits == 13 ? 1024 : kThreads << (row_bits - kXsRowBits);
+}
 
 template <typename ValT>
-XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl)
+XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl, int threads)
 {
-#define CGA_XS_CASE(W, RB, EPL)                                                         \
-  if (weighted == W && row_bits == RB && epl == EPL)                                    \
-    return XsKernelChoice<ValT>{xs_kernel<ValT, W, xs_threads_for(RB), RB, EPL>,        \
-                                xs_threads_for(RB), static_cast<int>(sizeof(double)) << RB};
-  CGA_XS_CASE(false, 12, 8)
-  CGA_XS_CASE(false, 13, 8)
-  CGA_XS_CASE(false, 14, 8)
-  CGA_XS_CASE(true, 12, 8)
-  CGA_XS_CASE(true, 13, 8)
-  CGA_XS_CASE(true, 14, 8)
+#define CGA_XS_CASE(W, RB, EPL, TH, WPE)                                                  \
+  if (weighted == W && row_bits == RB && epl == EPL && threads == TH)                     \
+    return XsKernelChoice<ValT>{xs_kernel<ValT, W, TH, RB, EPL, WPE>, TH,                 \
+                                static_cast<int>(sizeof(double)) << RB};
+  CGA_XS_CASE(false, 12, 8, 256, 1)
+  CGA_XS_CASE(false, 13, 8, 512, 1)
+  CGA_XS_CASE(false, 14, 8, 1024, 1)
+  CGA_XS_CASE(true, 12, 8, 256, 1)
+  CGA_XS_CASE(true, 13, 8, 512, 1)
+  CGA_XS_CASE(true, 14, 8, 1024, 1)
+  if constexpr (sizeof(ValT) == 4) {  // (the fp64 kernel needs more than 64 registers)
+    CGA_XS_CASE(false, 13, 8, 1024, 8)
+  }
 #undef CGA_XS_CASE
   throw Failure(CUGRAPH_UNKNOWN_ERROR, "internal: no xs_kernel for this tile layout");
 }
@@ -1510,6 +1724,13 @@ inline int grid_for(int64_t items, int cap = 256 * 16)
 
 #ifdef CGA_TIMING_AIDS
 // (make AIDS=1) {gathers of region-0 launches beyond the region, region-0 launches checked} so far
+// (make AIDS=1) xs_check_buf: violations of xs_kernel's address bounds so far and the first one
+void xs_bounds_check_read(unsigned long long* out)
+{
+  CGA_HIP(hipDeviceSynchronize());
+  CGA_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(xs_check_buf), 8 * sizeof(unsigned long long)));
+}
+
 void xs_region_check_read(unsigned long long* out)
 {
   CGA_HIP(hipDeviceSynchronize());
@@ -1550,6 +1771,7 @@ struct PullPlan {
   int64_t xs_partial_len{0};
   int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
   int xs_epl{kXsEntriesPerLane};  // entries a lane of xs_kernel keeps in flight per pass
+  int xs_threads{kThreads};       // threads of an xs_kernel workgroup (xs_threads_for)
   DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec[2], xs_pbase, xs_fin_items;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
@@ -1679,6 +1901,13 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
   if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
   int const epl = kXsEntriesPerLane;  // (4: 1.94 ms, 16: 1.77 ms against 1.75 ms at scale 26)
+  // Wide workgroups (unweighted graphs): 8192-row tiles run by two 1024-thread workgroups per CU
+  // instead of 16384-row tiles run by one (see xs_kernel's WPE).  CUGRAPH_AMD_XS_WIDE=0/1.
+  char const* wide_env = std::getenv("CUGRAPH_AMD_XS_WIDE");
+  bool wide = g.weights == nullptr && sizeof(ValT) == 4 && row_bits >= 13 && (wide_env ? std::atoi(wide_env) != 0 : kXsWideDefault);
+  if (wide && !rb_env) row_bits = 13;
+  wide = wide && row_bits == 13;
+  int const threads = xs_threads_for(row_bits, wide);
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
@@ -1781,7 +2010,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   char const* pc_env     = std::getenv("CUGRAPH_AMD_XS_PIECE");
   // a piece is 64 passes of its workgroup (128 of a 256-thread one); small graphs: down to 16, so
   // that there are a few thousand pieces
-  int64_t const pass_entries = int64_t(xs_threads_for(row_bits)) * epl;
+  int64_t const pass_entries = int64_t(threads) * epl;
   int64_t piece_entries      = row_bits == kXsRowBits ? kXsPieceEntries : 64 * pass_entries;
   while (piece_entries > 16 * pass_entries && piece_entries * 1024 > ne) piece_entries >>= 1;
   if (pc_env) piece_entries = std::atoll(pc_env);
@@ -1813,11 +2042,12 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // only tiles with enough entries per part take it; the low-degree tiles follow as whole units.
   char const* pw_env = std::getenv("CUGRAPH_AMD_XS_PART_WINDOWS");
   char const* pm_env = std::getenv("CUGRAPH_AMD_XS_PHASE_MIN");
-  int const part_windows  = pw_env ? std::atoi(pw_env) : 3;
+  // (3 windows of a 16384-row tile = 3 << 18 slice-local positions; 8192-row tiles: 2 windows of twice that)
+  int const part_windows  = pw_env ? std::atoi(pw_env) : row_bits == kXsRowBitsMax ? 3 : 2;
   int64_t const phase_min = pm_env ? std::atoll(pm_env) : (int64_t(1) << 18);  // entries per unit
   // (only for 16384-row tiles, the layout the parts were measured and run at full size with: graphs
   // whose source space needs 4096- or 8192-row tiles keep whole-unit items)
-  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows && row_bits == kXsRowBitsMax)
+  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows && (row_bits == kXsRowBitsMax || wide))
                         ? (n_win + part_windows - 1) / part_windows : 1;
   std::vector<XsItem> h_items[2];
   std::vector<std::vector<XsItem>> part_items(n_parts);  // region 0 of phased tiles, by part
@@ -1914,6 +2144,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_slice_shift = slice_shift;
   plan.xs_row_bits  = row_bits;
   plan.xs_epl       = epl;
+  plan.xs_threads   = threads;
 }
 
 template <typename OffT>
@@ -2283,7 +2514,7 @@ int session_geometry(Session& s, PullPlan& plan)
   if (s.xs_on) {
     // the kernel instantiation for this plan's tiles, and as many workgroups as are resident at
     // once (LDS- and register-bound: asked of the runtime), capped by the work items there are
-    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl);
+    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl, plan.xs_threads);
     CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(ch.kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ch.lds));
     int per_cu = 0, n_cu = 0;
@@ -2579,6 +2810,8 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.affinity_mode = am ? std::atoi(am) : 0;
     a.xs.profile       = std::getenv("CUGRAPH_AMD_XS_PROFILE") != nullptr && !g.weights;
     a.xs.no_atomics    = std::getenv("CUGRAPH_AMD_XS_NO_ATOMICS") != nullptr;
+    a.xs.no_gather     = std::getenv("CUGRAPH_AMD_XS_NO_GATHER") != nullptr;
+    a.xs.no_writeback  = std::getenv("CUGRAPH_AMD_XS_NO_WRITEBACK") != nullptr;
   }
 #endif
   a.vertex_first    = g.vertex_first;
@@ -2607,6 +2840,11 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     a.xs.row_first = plan.xs_row_first;
     a.xs.n_rows    = plan.xs_n_rows;
     a.xs.n_tiles   = plan.xs_n_tiles;
+#ifdef CGA_TIMING_AIDS
+    a.xs.ent_len     = plan.xs_n_edges + 4;
+    a.xs.partial_len = plan.xs_partial_len;
+    a.xs.x_len       = static_cast<uint32_t>(std::min<int64_t>(s.x_len, 0xFFFFFFFFLL));
+#endif
     if (phase != 1) CGA_HIP(hipMemsetAsync(s.xs_counters.p, 0, 256, stream));  // both regions' queues
   }
   for (int b = 0; b < kNumBuckets; ++b) a.buckets[b] = s.buckets[b];
@@ -2652,6 +2890,9 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     XsLaunch<ValT> xl{a.xs, a.x_cur, a.scal, a.ctrl, a.epsilon};
     auto kern = reinterpret_cast<void (*)(XsLaunch<ValT>)>(s.xs_kernel_fn);
     hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(s.xs_threads), s.xs_lds_bytes, stream, xl);
+#ifdef CGA_XS_PHASE_PROF
+    if (s.enqueued >= 3 && s.enqueued < 6) hipLaunchKernelGGL(xs_phase_dump_kernel, dim3(1), dim3(1), 0, stream);
+#endif
 #ifdef CGA_TIMING_AIDS
     if (a.xs.profile && s.enqueued == 3)
       hipLaunchKernelGGL(xs_prof_dump_kernel, dim3(1), dim3(1), 0, stream, std::min(s.n_xs_blocks, 1024));
