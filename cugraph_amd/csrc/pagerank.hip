@@ -22,8 +22,10 @@
 // epsilon, so the host can enqueue iterations ahead and read {iterations, stopped} back only now
 // and then.  Degree-bucketed load balancing (north_star): G lanes per destination with
 // G = 1 (thread per vertex), 16, 64 (wave64 per vertex, DPP/shuffle reduction) and one workgroup
-// per hub with LDS-staged partial sums; all buckets run in ONE launch, hubs first.
-// The path is a sparse HBM-bound contraction: no MFMA.
+// per hub with LDS-staged partial sums, all in one spmv_kernel launch -- on a graph that is too
+// small for them or not degree-sorted.  Otherwise the rows of in-degree >= 4 run as XS tiles in a
+// launch of their own (xs_kernel / xs2_kernel + xs_finish_kernel) and spmv_kernel keeps the
+// thread-per-row and isolated buckets.  The path is a sparse HBM-bound contraction: no MFMA.
 #include "common.hpp"
 
 #include <algorithm>
@@ -54,12 +56,15 @@ constexpr int64_t kXsPieceEntries = 1 << 18;  // entries of one work item: longe
 constexpr int kXsRowBits      = 12;
 constexpr int kXsRowBitsMax   = 14;
 constexpr int kXsMinDegree    = kLowDegreeMax + 1;
-#ifdef CGA_XS_NO_DENSE
-constexpr bool kXsDense = false;
-#else
-constexpr bool kXsDense = true;  // dense passes of xs_kernel: one coalesced load + cross-lane reads
+// (measured and dropped, profiles/r3_xs_diag.md: "dense" passes -- one coalesced load of the few dozen
+// consecutive source positions a pass over a hot stretch names, and ds_bpermute reads from it)
+// entries the first pass of an item is aligned down to: 64 = every wave load of 256 bytes is two
+// whole cache lines
+#ifndef CGA_XS_ALIGN
+#define CGA_XS_ALIGN 64
 #endif
-constexpr bool kXsWideDefault = false;  // two 1024-thread workgroups per CU on 8192-row tiles (build_xs)
+constexpr bool kXsWideDefault = false;
+constexpr bool kXsAsyncDefault = false;  // two 1024-thread workgroups per CU on 8192-row tiles (build_xs)
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
 // a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile
@@ -589,6 +594,15 @@ __global__ void xs_phase_dump_kernel()
          xs_phase_buf[1] + xs_phase_buf[2] + xs_phase_buf[3] + xs_phase_buf[4]);
   for (int i = 0; i < 8; ++i) xs_phase_buf[i] = 0;
 }
+__global__ void xs2_phase_dump_kernel()
+{
+  double const w = 1.0;
+  printf("XS2PHASE wave-passes %llu | sums over waves (ticks): wait-record %.3g wait-bank %.3g produce %.3g setup %.3g passes %.3g "
+         "leave+writeback %.3g kernel %.3g | per pass %.0f\n",
+         xs_phase_buf[0], w * xs_phase_buf[1], w * xs_phase_buf[2], w * xs_phase_buf[3], w * xs_phase_buf[4], w * xs_phase_buf[5],
+         w * xs_phase_buf[6], w * xs_phase_buf[7], (double)xs_phase_buf[5] / xs_phase_buf[0]);
+  for (int i = 0; i < 8; ++i) xs_phase_buf[i] = 0;
+}
 #define CGA_PH(stmt) do { stmt; } while (0)
 #else
 #define CGA_PH(stmt) do { } while (0)
@@ -599,6 +613,14 @@ __global__ void xs_phase_dump_kernel()
 __device__ inline void lds_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// accumulators per row of a tile, as a power of two: as many as fit the bank, 64 at most
+__device__ inline int xs_rep_bits(int rows, int bank_rows)
+{
+  int const fit = bank_rows / (rows > 0 ? rows : 1);  // >= 1
+  int const b   = 31 - __builtin_clz(static_cast<unsigned int>(fit));
+  return b < 6 ? b : 6;
 }
 
 // One workgroup pulls work items (pieces of (tile, slice) units) from the queue of the XCD it runs
@@ -692,9 +714,13 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
       uint32_t const n_pc  = static_cast<uint32_t>(head >> 40) & 0xffu;
       int const rows    = static_cast<int>(uniform64(rec[1]) >> 32);
       ValT* const out   = xs.partial + uniform64(rec[2]);
-      // tiles of at most 4 (long) rows: 64 lanes adding to the same LDS word would serialise, so
-      // every lane adds into LDS words of its own and wave 0 folds them at the end of the item
-      bool const few = rows <= 4;
+      // Tiles of FEW rows (the hub tiles: 131 rows share 16.8 M entries in the first tile of a
+      // scale-26 graph): lanes of one atomic instruction that add to the same row serialise in the
+      // LDS, and such tiles ran at half the speed of their entry stream (profiles/r3_xs_tiles.md).
+      // A row therefore gets 2^rep accumulators, as many as fit (up to 64), and a lane adds into
+      // the one its lane number selects; the write-back adds a row's accumulators in a fixed order.
+      int const rep          = xs_rep_bits(rows, 1 << ROWBITS);
+      uint32_t const rep_sel = static_cast<uint32_t>(lane) & ((1u << rep) - 1u);
       // the (tile, slice) stream is the concatenation of its windows: an entry's window follows
       // from its position.  bound(w): first position of window w relative to the aligned start
       // (0 for a window that starts before this item's entries -- an item can be the tail of a
@@ -702,7 +728,7 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
       int64_t const u0    = ((int64_t)t * kXsSlices + k) * n_win;
       int64_t const beg   = uniform64(rec[3]);
       int64_t const end   = uniform64(rec[4]);
-      int64_t const abeg  = beg & ~int64_t(3);
+      int64_t const abeg  = beg & ~int64_t(CGA_XS_ALIGN - 1);
       uint32_t const rbeg = static_cast<uint32_t>(beg - abeg);
       uint32_t const rend = static_cast<uint32_t>(end - abeg);
       auto bound = [&](int w) -> uint32_t {
@@ -811,42 +837,26 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
 #endif
 #endif
         };
-        // DENSE passes.  The entries of a unit ascend by source, so the 512 entries of a pass over a
-        // hot stretch of the source space (a hub tile's hot window: tens of entries per source)
-        // name only a few dozen consecutive source positions -- and as eight gather instructions
-        // they hit the same one or two cache lines eight times, most of them while the line is
-        // still on its way from L2: the L1 stalls on every such hit (TCP_PENDING_STALL_CYCLES: 63 %
-        // of xs_kernel's cycles, profiles/r3_xs_diag.md; why neither more waves nor more loads in
-        // flight made the kernel faster).  When the pass spans fewer than 64 (128) positions the wave
-        // loads that stretch of x ONCE, lane l taking position first + l (one or two coalesced
-        // loads), and every entry takes its value from the lane that holds it (ds_bpermute: the
-        // LDS crossbar, no memory access).
-        int dense = 0;
-        ValT xd0 = ValT(0), xd1 = ValT(0);
-        uint32_t s_first = 0u;
         if constexpr (FAST) {
-          uint32_t const s_last = __builtin_amdgcn_readlane(en[EPL - 1] >> ROWBITS, 63);
-          s_first               = __builtin_amdgcn_readfirstlane(en[0] >> ROWBITS);
-          uint32_t const span   = s_last - s_first;
-          dense                 = kXsDense ? (span < 64u ? 1 : span < 128u ? 2 : 0) : 0;
-          if (dense) {
-            // (positions up to the pass's last one exist; the lanes beyond it re-read that one)
-            uint32_t p0 = s_first + static_cast<uint32_t>(lane);
-            p0          = p0 < s_last ? p0 : s_last;
-            xd0         = gather1(static_cast<uint32_t>(w_lo), ((p0 & ~low_mask) << 3) | (p0 & low_mask));
-            if (dense == 2) {
-              uint32_t p1 = s_first + 64u + static_cast<uint32_t>(lane);
-              p1          = p1 < s_last ? p1 : s_last;
-              xd1         = gather1(static_cast<uint32_t>(w_lo), ((p1 & ~low_mask) << 3) | (p1 & low_mask));
-            }
-          } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            uint32_t const lo = en[e] >> ROWBITS;
+            xv[e]             = gather1(static_cast<uint32_t>(w_lo), ((lo & ~low_mask) << 3) | (lo & low_mask));
+          }
+        } else {
+          // windows the pass may span with 32-bit byte offsets from the first one's base
+          constexpr int kSpanMax = 1 << (29 - kLowBits - (sizeof(ValT) == 8 ? 3 : 2));
+          if (w_hi - w_lo < kSpanMax) {
+            // one gather per entry, its window folded into the offset (entries that are not the
+            // item's read the window's first slot)
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
               uint32_t const lo = en[e] >> ROWBITS;
-              xv[e]             = gather1(static_cast<uint32_t>(w_lo), ((lo & ~low_mask) << 3) | (lo & low_mask));
+              uint32_t const of = ((wn[e] - static_cast<uint32_t>(w_lo)) << (kLowBits + 3)) | ((lo & ~low_mask) << 3) | (lo & low_mask);
+              ValT const v      = gather1(static_cast<uint32_t>(w_lo), p[e] ? of : 0u);
+              xv[e]             = p[e] ? v : ValT(0);
             }
-          }
-        } else {
+          } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) xv[e] = ValT(0);
           for (int wi = w_lo; wi <= w_hi; ++wi) {
@@ -860,25 +870,12 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
               xv[e]             = mine ? v : xv[e];
             }
           }
+          }
         }
         uint32_t en_next[EPL];
         ValT w_next[EPL];
         if (have_next) fetch(pb_next, en_next, w_next);
         CGA_PH(unsigned long long const t2 = clock64(); ph_issue += t2 - ph_t; ph_t = t2);
-        if constexpr (FAST) {
-          if (dense == 1) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) xv[e] = __shfl(xd0, static_cast<int>((en[e] >> ROWBITS) - s_first), 64);
-          } else if (dense == 2) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              uint32_t const d = (en[e] >> ROWBITS) - s_first;
-              ValT const v0    = __shfl(xd0, static_cast<int>(d & 63u), 64);
-              ValT const v1    = __shfl(xd1, static_cast<int>(d & 63u), 64);
-              xv[e]            = d < 64u ? v0 : v1;
-            }
-          }
-        }
         if constexpr (WEIGHTED) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
@@ -892,30 +889,34 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
           ph_t = t3;
         }
 #endif
-        if (few) {
-          // every lane adds into words of its own: 64 accumulators per row behind the (at most 4)
-          // row sums, folded after the item's passes
-#pragma unroll
-          for (int e = 0; e < EPL; ++e)
-            if (p[e]) atomicAdd(&acc[4 + ((en[e] & 3u) << 6) + lane], static_cast<double>(xv[e]));
 #ifdef CGA_TIMING_AIDS
-        } else if (xs.no_atomics) {
+        if (xs.no_atomics) {
           ValT sum = 0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
           if (sum == ValT(-1)) atomicAdd(&acc[0], 1.0);
+        } else
 #endif
 #if defined(CGA_XS_ABL_NOATOM)
-        } else if (true) {
+        if (true) {
           ValT sum = 0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
           if (sum == ValT(-1)) atomicAdd(&acc[0], 1.0);
+        } else
 #endif
-        } else {
+        {
 #pragma unroll
           for (int e = 0; e < EPL; ++e)
-            if (p[e]) atomicAdd(&acc[en[e] & kRowMask], static_cast<double>(xv[e]));
+#if defined(CGA_XS_ABL_U64)
+            if (p[e]) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (((en[e] & kRowMask) << rep) | rep_sel),
+                                static_cast<unsigned long long>(__float_as_uint(static_cast<float>(xv[e]))));
+#elif defined(CGA_XS_ABL_U32)
+            if (p[e]) atomicAdd(reinterpret_cast<unsigned int*>(acc) + (((en[e] & kRowMask) << rep) | rep_sel),
+                                __float_as_uint(static_cast<float>(xv[e])));
+#else
+            if (p[e]) atomicAdd(&acc[((en[e] & kRowMask) << rep) | rep_sel], static_cast<double>(xv[e]));
+#endif
         }
         CGA_PH(unsigned long long const t4 = clock64(); ph_acc += t4 - ph_t; ph_t = t4; ph_n += 1; ph_fast += FAST ? 1 : 0);
         if (have_next) {
@@ -937,7 +938,10 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
       CGA_PH(unsigned long long const tb = clock64(); ph_bound += tb - ph_end; ph_t = tb);
       while (i0 < n_wp) {
         uint32_t const pb = pb_lo + i0 * kWavePass, pe = pb + kWavePass;
-        uint32_t const i2 = claim();
+        // (the claim of the pass after next is asked for here and looked at when this pass is done:
+        // the LDS serves it behind every queued atomic of the workgroup, which is not waited for)
+        unsigned int i2_raw = 0;
+        if (lane == 0) i2_raw = atomicAdd(&s_claim, 1u);
         // windows that end before this pass were another wave's
         while (nb <= pb && w_cur + 1 < n_win) {
           ++w_cur;
@@ -962,23 +966,13 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
           rec_asked = true;
         }
         i0 = i1;
-        i1 = i2;
+        i1 = __builtin_amdgcn_readfirstlane(i2_raw);
         CGA_PH(ph_t = clock64());
       }
       CGA_PH(ph_end = clock64());
       if (wave0 && !rec_asked) r_next = load_record(k, __shfl(q_next, 0));
       CGA_XSP(pt_a = wall_clock64());
       __syncthreads();
-      if (few && wave0) {
-        // (thread 0 writes rows 0..3 back: the same wave, so its LDS reads follow these writes)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          double v               = acc[4 + (rr << 6) + lane];
-          acc[4 + (rr << 6) + lane] = 0.0;
-          v                      = group_sum(v, 64);
-          if (lane == 0) acc[rr] = v;
-        }
-      }
       CGA_XSP(pt_c = wall_clock64(); pt_b1 += pt_c - pt_a);
       // the partials of a tile are padded to a multiple of 4 rows (build_xs): whole vectors
       int const rows4 = (rows + 3) & ~3;
@@ -987,6 +981,25 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
       // the passes of every item)
       int tw = tid;
       asm volatile("" : "+v"(tw));
+      if (rep > 0) {
+        // a row's 2^rep accumulators are neighbours: one row per thread and trip
+        for (int i = tw; i < rows4; i += THREADS) {
+          double sum = 0.0;
+          for (int q = 0; q < (1 << rep); q += 2) {
+            v2f64_t* const pa = reinterpret_cast<v2f64_t*>(acc + (i << rep) + q);
+            v2f64_t const v   = *pa;
+            sum += v.x + v.y;
+            *pa = v2f64_t{0.0, 0.0};
+          }
+#ifdef CGA_TIMING_AIDS
+          if ((out - xs.partial) + i < 0 || (out - xs.partial) + i >= xs.partial_len) {
+            CGA_XS_CHECK(true, 3, out - xs.partial, i);
+          } else if (xs.no_writeback) {
+          } else
+#endif
+          __builtin_nontemporal_store(static_cast<ValT>(sum), out + i);
+        }
+      } else
       for (int i = tw * 4; i < rows4; i += THREADS * 4) {
         v2f64_t const s0 = *reinterpret_cast<v2f64_t const*>(acc + i);
         v2f64_t const s1 = *reinterpret_cast<v2f64_t const*>(acc + i + 2);
@@ -1036,6 +1049,467 @@ __global__ __launch_bounds__(THREADS, WPE) void xs_kernel(XsLaunch<ValT> a)
 #endif
 }
 
+
+// ---- xs_kernel without workgroup-wide item boundaries.
+// In xs_kernel the 16 waves of a workgroup finish an item together: barrier, write-back, barrier,
+// re-fill -- ~25 000 clock ticks (11 us) per item in which the workgroup streams nothing, 30 % of a
+// wave's time at scale 26 and most of it for the 600 tiles of low-degree rows, whose units are
+// three wave passes long (profiles/r3_xs_phases.md).  Here the workgroup keeps TWO banks of row
+// accumulators (8192-row tiles: 2 x 64 KiB) and consecutive items alternate between them, so a wave
+// that finds no pass left in item j walks on into item j + 1 while the others finish j; the LAST
+// wave to leave an item writes its bank back, clears it and hands it to item j + 2.  No barrier
+// after the start of the kernel.  The control words live in LDS:
+//   s_ready[j & 3] == j + 1   the record of item j is in s_rec[j & 3] (written by the first wave that
+//                             entered item j - 2; the queue pop and the record load are its two
+//                             round trips to memory, two items ahead of their use)
+//   s_bank_item[j & 1] == j   bank j & 1 is clear and its counters are reset for item j
+//   s_claim[b], s_left[b]     next wave pass of the bank's item; waves that have not left it yet
+// Waits are spins on those words with s_sleep; every spin gives up after kXsSpinLimit rounds and
+// raises ctrl->done with the error bit (a logic error then ends the kernel instead of hanging it).
+constexpr int kXs2Threads   = 1024;
+constexpr int kXs2Waves     = kXs2Threads / 64;
+constexpr unsigned int kXsSpinLimit = 1u << 24;
+
+template <typename ValT, bool WEIGHTED, int ROWBITS, int EPL>
+__global__ __launch_bounds__(kXs2Threads) void xs2_kernel(XsLaunch<ValT> a)
+{
+  constexpr int kLowBits       = 32 - ROWBITS;
+  constexpr uint32_t kRowMask  = (1u << ROWBITS) - 1u;
+  constexpr uint32_t kPass     = kXs2Threads * EPL;  // granule of a piece's share of its unit (xs_records_kernel)
+  constexpr uint32_t kWavePass = 64 * EPL;           // entries of one wave pass
+  constexpr int kRows          = 1 << ROWBITS;
+  extern __shared__ double xs_lds[];  // [2][kRows]
+  __shared__ int64_t s_rec[4][kXsRecWords];
+  __shared__ unsigned int s_ready[4], s_enter[4], s_claim[2], s_left[2], s_bank_item[2], s_rot, s_fail;
+  // write-back of a bank, shared by the waves that have nothing else to do: s_wb_claim[b] ==
+  // (j + 1) << 8 | c says item j's bank is being written back and chunk c (kWbRows rows) is the next
+  // to take -- taken by compare-and-swap, so that a wave that looks late never takes a chunk of a
+  // later item's write-back; finished chunks are counted in s_wb_done[b], and the wave that finishes
+  // the last one hands the bank to item j + 2
+  __shared__ unsigned int s_wb_claim[2], s_wb_done[2];
+  constexpr int kWbRows = 512;
+  if (stop_check(a.ctrl, a.scal, a.epsilon, false)) return;
+  XsArgs<ValT> const& xs = a.xs;
+  int const tid  = threadIdx.x;
+  int const lane = tid & 63;
+  int const my   = static_cast<int>(xcc_id() & (kXsSlices - 1));
+  for (int i = tid; i < 2 * kRows; i += kXs2Threads) xs_lds[i] = 0.0;
+  if (tid < 4) {
+    s_ready[tid] = 0u;
+    s_enter[tid] = 0u;
+  }
+  if (tid < 2) {
+    s_claim[tid]     = 0u;
+    s_left[tid]      = kXs2Waves;
+    s_bank_item[tid] = static_cast<unsigned int>(tid);
+    s_wb_claim[tid]  = 0u;
+    s_wb_done[tid]   = 0u;
+  }
+  if (tid == 0) {
+    s_rot  = 0u;
+    s_fail = 0u;
+  }
+  __syncthreads();
+#ifdef CGA_XS_PHASE_PROF
+  // [0] passes [1] wait for record [2] wait for bank [3] produce [4] setup [5] passes [6] leave + write-back [7] kernel
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long const ph_k0 = clock64();
+  unsigned long long ph_t = ph_k0;
+#define CGA_PH2(i) do { unsigned long long const t_ = clock64(); ph[i] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define CGA_PH2(i) do { } while (0)
+#endif
+  int const shift         = xs.slice_shift;
+  uint32_t const low_mask = (1u << shift) - 1u;
+  int const n_win         = xs.n_win;
+  auto lds_word = [&](unsigned int* p) -> unsigned int {
+    return __builtin_amdgcn_readfirstlane(*reinterpret_cast<unsigned int volatile*>(p));
+  };
+  // wait until *p == want; false: gave up (somebody failed, or the spin limit)
+  auto wait_for = [&](unsigned int* p, unsigned int want) -> bool {
+    for (unsigned int spins = 0; spins < kXsSpinLimit; ++spins) {
+      if (lds_word(p) == want) return true;
+      if ((spins & 63u) == 63u && lds_word(&s_fail) != 0u) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) {
+      s_fail       = 1u;
+      a.ctrl->done = 3;  // stopped | internal error: session_status reports it
+    }
+    return false;
+  };
+  // Takes chunks of the bank of item jj (its record is still in s_rec[jj & 3]) until none is left:
+  // partials out, accumulators cleared.  Whoever finishes the last chunk resets the bank's
+  // counters and hands it to item jj + 2.
+  auto write_back = [&](unsigned int jj) {
+    unsigned int const b  = jj & 1u;
+    int64_t const* rec    = s_rec[jj & 3u];
+    int const rows        = static_cast<int>(uniform64(rec[1]) >> 32);
+    ValT* const out       = xs.partial + uniform64(rec[2]);
+    double* const acc     = xs_lds + static_cast<size_t>(b) * kRows;
+    int const rows4       = (rows + 3) & ~3;  // partial sets are whole 4-row vectors (build_xs)
+    int const rep         = xs_rep_bits(rows, kRows);
+    int const chunk_rows  = kWbRows >> rep;  // a chunk is kWbRows accumulators
+    unsigned int const n_chunks = static_cast<unsigned int>((rows4 + chunk_rows - 1) / chunk_rows);  // 1 .. 16
+    unsigned int const tag      = (jj + 1u) << 8;
+    while (true) {
+      unsigned int c = 0u, got = 0u;
+      if (lane == 0) {
+        unsigned int v = *reinterpret_cast<unsigned int volatile*>(&s_wb_claim[b]);
+        while ((v & ~255u) == tag && (v & 255u) < n_chunks) {
+          unsigned int const old = atomicCAS(&s_wb_claim[b], v, v + 1u);
+          if (old == v) {
+            got = 1u;
+            break;
+          }
+          v = old;
+        }
+        c = v & 255u;
+      }
+      if (__builtin_amdgcn_readfirstlane(got) == 0u) return;
+      c = __builtin_amdgcn_readfirstlane(c);
+      int const r0 = static_cast<int>(c) * chunk_rows;
+      int const r1 = r0 + chunk_rows < rows4 ? r0 + chunk_rows : rows4;
+      if (rep > 0) {
+        for (int i = r0 + lane; i < r1; i += 64) {
+          double sum = 0.0;
+          for (int q = 0; q < (1 << rep); q += 2) {
+            v2f64_t* const pa = reinterpret_cast<v2f64_t*>(acc + (i << rep) + q);
+            v2f64_t const v   = *pa;
+            sum += v.x + v.y;
+            *pa = v2f64_t{0.0, 0.0};
+          }
+#ifdef CGA_TIMING_AIDS
+          if ((out - xs.partial) + i < 0 || (out - xs.partial) + i >= xs.partial_len) {
+            unsigned long long const t = 0, k = 0;
+            CGA_XS_CHECK(true, 3, out - xs.partial, i);
+          } else
+#endif
+          __builtin_nontemporal_store(static_cast<ValT>(sum), out + i);
+        }
+      } else
+      for (int i = r0 + lane * 4; i < r1; i += 256) {
+        v2f64_t const s0 = *reinterpret_cast<v2f64_t const*>(acc + i);
+        v2f64_t const s1 = *reinterpret_cast<v2f64_t const*>(acc + i + 2);
+        ValT const r4[4] = {static_cast<ValT>(s0.x), static_cast<ValT>(s0.y), static_cast<ValT>(s1.x),
+                            static_cast<ValT>(s1.y)};
+#ifdef CGA_TIMING_AIDS
+        if ((out - xs.partial) + i < 0 || (out - xs.partial) + i + 4 > xs.partial_len) {
+          unsigned long long const t = 0, k = 0;
+          CGA_XS_CHECK(true, 3, out - xs.partial, i);
+        } else
+#endif
+        stream_store_vals4(out + i, r4);
+        v2f64_t const z = {0.0, 0.0};
+        *reinterpret_cast<v2f64_t*>(acc + i)     = z;
+        *reinterpret_cast<v2f64_t*>(acc + i + 2) = z;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk is clear before it counts as done
+      unsigned int d = 0u;
+      if (lane == 0) d = atomicAdd(&s_wb_done[b], 1u);
+      if (__builtin_amdgcn_readfirstlane(d) + 1u == n_chunks) {
+        if (lane == 0) {
+          s_claim[b]    = 0u;
+          s_left[b]     = kXs2Waves;
+          s_wb_claim[b] = 0u;
+          s_wb_done[b]  = 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *reinterpret_cast<unsigned int volatile*>(&s_bank_item[b]) = jj + 2u;
+        return;
+      }
+    }
+  };
+  // Pops the next work item of this workgroup (own queue first, then the other slices') and parks
+  // its record in slot j & 3; the whole wave runs it.  Queue empty everywhere: the end marker.
+  auto produce = [&](unsigned int j) {
+    unsigned int rot = lds_word(&s_rot);
+    int64_t r        = -1;
+    while (rot < static_cast<unsigned int>(kXsSlices)) {
+      int const k = (my + static_cast<int>(rot)) & (kXsSlices - 1);
+      int q       = 0;
+      if (lane == 0) q = atomicAdd(&xs.counters[k], 1);
+      q = __builtin_amdgcn_readfirstlane(q);
+      if (q < xs.n_items) {
+        r = xs.rec[(static_cast<int64_t>(k) * xs.n_items + q) * kXsRecWords + lane];
+        if (lane == 0) r |= static_cast<int64_t>(k) << 48;  // the slice travels in the head word
+        break;
+      }
+      ++rot;
+    }
+    s_rec[j & 3u][lane] = r;
+    if (lane == 0) {
+      atomicMax(&s_rot, rot);
+      s_enter[j & 3u] = 0u;
+    }
+    // (one wave's LDS operations execute in order: the record is in place before the tag says so)
+    if (lane == 0) *reinterpret_cast<unsigned int volatile*>(&s_ready[j & 3u]) = j + 1u;
+  };
+  if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+    produce(0u);
+    produce(1u);
+  }
+  for (unsigned int j = 0;; ++j) {
+    unsigned int const slot = j & 3u, bank = j & 1u;
+    if (!wait_for(&s_ready[slot], j + 1u)) return;
+    CGA_PH2(1);
+    int64_t const* rec = s_rec[slot];
+    int64_t const head = uniform64(rec[0]);  // tile | piece << 32 | pieces << 40 | slice << 48
+    if (head < 0) break;
+    // the bank belongs to item j - 2 until that is written back: lend a hand, then wait
+    if (j >= 2u && lds_word(&s_bank_item[bank]) != j) {
+      for (unsigned int spins = 0; spins < kXsSpinLimit; ++spins) {
+        if ((lds_word(&s_wb_claim[bank]) & ~255u) == (j - 1u) << 8) {
+          write_back(j - 2u);
+          break;
+        }
+        if (lds_word(&s_bank_item[bank]) == j) break;
+        if ((spins & 63u) == 63u && lds_word(&s_fail) != 0u) return;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (!wait_for(&s_bank_item[bank], j)) return;
+    CGA_PH2(2);
+    {
+      unsigned int first = 0u;
+      if (lane == 0) first = atomicAdd(&s_enter[slot], 1u);
+      if (__builtin_amdgcn_readfirstlane(first) == 0u) {
+        // (queue pops in item order: once one item is the end marker, every later one is)
+        if (!wait_for(&s_ready[(j + 1u) & 3u], j + 2u)) return;
+        produce(j + 2u);
+      }
+    }
+    CGA_PH2(3);
+    double* const acc          = xs_lds + static_cast<size_t>(bank) * kRows;
+    unsigned int* const claimp = &s_claim[bank];
+    int const t          = static_cast<int>(head & 0xffffffff);
+    uint32_t const piece = static_cast<uint32_t>(head >> 32) & 0xffu;
+    uint32_t const n_pc  = static_cast<uint32_t>(head >> 40) & 0xffu;
+    int const k          = static_cast<int>(head >> 48) & (kXsSlices - 1);
+    uint32_t const kbits = static_cast<uint32_t>(k) << shift;
+    int const rows       = static_cast<int>(uniform64(rec[1]) >> 32);
+    int const rep          = xs_rep_bits(rows, kRows);  // accumulators per row: see xs_kernel
+    uint32_t const rep_sel = static_cast<uint32_t>(lane) & ((1u << rep) - 1u);
+    int64_t const u0     = ((int64_t)t * kXsSlices + k) * n_win;
+    int64_t const beg    = uniform64(rec[3]);
+    int64_t const end    = uniform64(rec[4]);
+    int64_t const abeg   = beg & ~int64_t(CGA_XS_ALIGN - 1);
+    uint32_t const rbeg  = static_cast<uint32_t>(beg - abeg);
+    uint32_t const rend  = static_cast<uint32_t>(end - abeg);
+    auto bound = [&](int w) -> uint32_t {
+      if (w <= 0) return 0u;
+      if (w >= n_win) return 0xFFFFFFFFu;
+      int64_t const s = w < kXsRecWindows ? uniform64(rec[4 + w]) : xs.unit_off[u0 + w];
+      int64_t const d = s - abeg;
+      return d > 0xFFFFFFFELL ? 0xFFFFFFFFu : d < 0 ? 0u : static_cast<uint32_t>(d);
+    };
+    auto claim = [&]() -> uint32_t {
+      unsigned int c = 0;
+      if (lane == 0) c = atomicAdd(claimp, 1u);
+      return __builtin_amdgcn_readfirstlane(c);
+    };
+    uint32_t const n_pass = (rend + kPass - 1) / kPass;
+    uint32_t const pb_lo  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * piece / n_pc) * kPass;
+    uint32_t const pb_hi  = static_cast<uint32_t>(static_cast<uint64_t>(n_pass) * (piece + 1) / n_pc) * kPass;
+    uint32_t const pb_end = pb_hi < rend ? pb_hi : rend;
+    uint32_t const n_wp   = pb_end > pb_lo ? (pb_end - pb_lo + kWavePass - 1) / kWavePass : 0u;
+    uint32_t i0 = claim();
+    CGA_PH2(4);
+    if (i0 < n_wp) {
+      uint32_t i1 = claim();
+      int w_cur = 0;
+      {
+        uint32_t const p0 = pb_lo + i0 * kWavePass > rbeg ? pb_lo + i0 * kWavePass : rbeg;
+        int lo = 0, hi = n_win - 1;
+        while (lo < hi) {
+          int const mid = (lo + hi + 1) >> 1;
+          if (bound(mid) <= p0) lo = mid; else hi = mid - 1;
+        }
+        w_cur = lo;
+      }
+      uint32_t nb = bound(w_cur + 1);  // where the next window starts
+      uint32_t const q_last = (rend > 0 ? rend : 1u) - 1u;
+      uint32_t en[EPL];
+      ValT w[EPL];
+      auto fetch = [&](uint32_t pb, uint32_t* en_out, ValT* w_out) {
+        uint32_t const pbc = pb < q_last ? pb : q_last;
+        uint32_t lim       = q_last - pbc;
+        int64_t first      = abeg + static_cast<int64_t>(pbc);
+#ifdef CGA_TIMING_AIDS
+        if (first < 0 || first + lim >= xs.ent_len) {
+          CGA_XS_CHECK(true, 1, first, lim);
+          first = 0;
+          lim   = 0u;
+        }
+#endif
+        uint32_t const* const eb = xs.ent + first;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          uint32_t q = static_cast<uint32_t>(lane) + e * 64;
+          q          = q < lim ? q : lim;
+          en_out[e]  = __builtin_nontemporal_load(eb + q);
+          if constexpr (WEIGHTED) w_out[e] = __builtin_nontemporal_load(xs.w + first + q);
+        }
+      };
+      auto pass = [&](auto fast_tag, uint32_t pb, uint32_t pb_next, bool have_next, int w_lo, int w_hi) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        uint32_t const pos = pb + static_cast<uint32_t>(lane);
+        bool p[EPL];
+        uint32_t wn[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          uint32_t q = pos + e * 64;
+          p[e]       = FAST || (q >= rbeg && q < rend);
+          wn[e]      = static_cast<uint32_t>(w_lo);
+        }
+        if constexpr (!FAST) {
+          for (int wi = w_lo + 1; wi <= w_hi; ++wi) {
+            uint32_t const b = bound(wi);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) wn[e] += pos + e * 64 >= b ? 1u : 0u;
+          }
+        }
+        ValT xv[EPL];
+        auto gather1 = [&](uint32_t wi, uint32_t off) -> ValT {
+#ifdef CGA_TIMING_AIDS
+          if (xs.no_gather) return ValT(1);
+          uint32_t gi = ((wi << (kLowBits + 3)) | kbits) + off;
+          if (a.xs.slot_limit != 0u && gi >= a.xs.slot_limit) atomicAdd(&xs_region_check[0], 1ull);
+          if (gi >= xs.x_len) {
+            CGA_XS_CHECK(true, 2, gi, (static_cast<uint64_t>(wi) << 32) | off);
+            gi = 0u;
+          }
+          return a.x_cur[CGA_GMASK(a.xs, gi)];
+#else
+          [[maybe_unused]] ValT const* const xb = a.x_cur + ((static_cast<uint64_t>(wi) << (kLowBits + 3)) | kbits);
+#if defined(CGA_XS_ABL_NOGATHER)
+          return ValT(1) + static_cast<ValT>(off & 1u);
+#elif defined(CGA_XS_ABL_MASK)
+          return xb[off & CGA_XS_ABL_MASK];
+#else
+          return xb[off];
+#endif
+#endif
+        };
+        if constexpr (FAST) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            uint32_t const lo = en[e] >> ROWBITS;
+            xv[e]             = gather1(static_cast<uint32_t>(w_lo), ((lo & ~low_mask) << 3) | (lo & low_mask));
+          }
+        } else {
+          // windows the pass may span with 32-bit byte offsets from the first one's base
+          constexpr int kSpanMax = 1 << (29 - kLowBits - (sizeof(ValT) == 8 ? 3 : 2));
+          if (w_hi - w_lo < kSpanMax) {
+            // one gather per entry, its window folded into the offset (entries that are not the
+            // item's read the window's first slot)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              uint32_t const lo = en[e] >> ROWBITS;
+              uint32_t const of = ((wn[e] - static_cast<uint32_t>(w_lo)) << (kLowBits + 3)) | ((lo & ~low_mask) << 3) | (lo & low_mask);
+              ValT const v      = gather1(static_cast<uint32_t>(w_lo), p[e] ? of : 0u);
+              xv[e]             = p[e] ? v : ValT(0);
+            }
+          } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) xv[e] = ValT(0);
+          for (int wi = w_lo; wi <= w_hi; ++wi) {
+            if (bound(wi + 1) <= bound(wi)) continue;  // no entry of this item in window wi
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              uint32_t const lo = en[e] >> ROWBITS;
+              bool const mine   = p[e] && wn[e] == static_cast<uint32_t>(wi);
+              ValT const v      = gather1(static_cast<uint32_t>(wi), mine ? ((lo & ~low_mask) << 3) | (lo & low_mask) : 0u);
+              xv[e]             = mine ? v : xv[e];
+            }
+          }
+          }
+        }
+        uint32_t en_next[EPL];
+        ValT w_next[EPL];
+        if (have_next) fetch(pb_next, en_next, w_next);
+        if constexpr (WEIGHTED) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) xv[e] *= w[e];
+        }
+#if defined(CGA_XS_ABL_NOATOM)
+        if (true) {
+          ValT sum = 0;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) sum += p[e] ? xv[e] + static_cast<ValT>(en[e] & kRowMask) : ValT(0);
+          if (sum == ValT(-1)) atomicAdd(&acc[0], 1.0);
+        } else
+#endif
+        {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e)
+#if defined(CGA_XS_ABL_U64)
+            if (p[e]) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (((en[e] & kRowMask) << rep) | rep_sel),
+                                static_cast<unsigned long long>(__float_as_uint(static_cast<float>(xv[e]))));
+#elif defined(CGA_XS_ABL_U32)
+            if (p[e]) atomicAdd(reinterpret_cast<unsigned int*>(acc) + (((en[e] & kRowMask) << rep) | rep_sel),
+                                __float_as_uint(static_cast<float>(xv[e])));
+#else
+            if (p[e]) atomicAdd(&acc[((en[e] & kRowMask) << rep) | rep_sel], static_cast<double>(xv[e]));
+#endif
+        }
+        if (have_next) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            en[e] = en_next[e];
+            if constexpr (WEIGHTED) w[e] = w_next[e];
+          }
+        }
+      };
+      fetch(pb_lo + i0 * kWavePass, en, w);
+      while (i0 < n_wp) {
+        uint32_t const pb = pb_lo + i0 * kWavePass, pe = pb + kWavePass;
+        // (the claim of the pass after next is asked for here and looked at when this pass is done:
+        // the LDS serves it behind every queued atomic of the workgroup, which is not waited for)
+        unsigned int i2_raw = 0;
+        if (lane == 0) i2_raw = atomicAdd(claimp, 1u);
+        while (nb <= pb && w_cur + 1 < n_win) {  // windows that end before this pass were another wave's
+          ++w_cur;
+          nb = bound(w_cur + 1);
+        }
+        bool const have_next   = i1 < n_wp;
+        uint32_t const pb_next = pb_lo + i1 * kWavePass;
+        if (pb >= rbeg && pe <= rend && pe <= nb) {
+          pass(std::true_type{}, pb, pb_next, have_next, w_cur, w_cur);
+        } else {
+          int w_hi = w_cur;
+          while (nb < pe && w_hi + 1 < n_win) {  // window w_hi + 1 starts inside this pass
+            ++w_hi;
+            nb = bound(w_hi + 1);
+          }
+          pass(std::false_type{}, pb, pb_next, have_next, w_cur, w_hi);
+          w_cur = w_hi;
+        }
+        i0 = i1;
+        i1 = __builtin_amdgcn_readfirstlane(i2_raw);
+        CGA_PH(ph[0] += 1);
+      }
+    }
+    CGA_PH2(5);
+    // ---- leave the item: this wave's LDS atomics have landed before it says so
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned int left = 0u;
+    if (lane == 0) left = atomicSub(&s_left[bank], 1u);
+    if (__builtin_amdgcn_readfirstlane(left) == 1u) {
+      // the last wave out: every other wave's atomics preceded its own decrement
+      if (lane == 0) *reinterpret_cast<unsigned int volatile*>(&s_wb_claim[bank]) = (j + 1u) << 8;
+      write_back(j);
+    }
+    CGA_PH2(6);
+  }
+#ifdef CGA_XS_PHASE_PROF
+  if (lane == 0) {
+    ph[7] = clock64() - ph_k0;
+    for (int i = 0; i < 8; ++i) atomicAdd(&xs_phase_buf[i], ph[i]);
+  }
+#endif
+}
+
 #ifdef CGA_TIMING_AIDS
 __global__ void xs_region_count_kernel() { xs_region_check[1] += 1ull; }
 
@@ -1065,8 +1539,20 @@ constexpr int xs_threads_for(int row_bits, bool wide = false)
 }
 
 template <typename ValT>
-XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl, int threads)
+XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl, int threads, bool async)
 {
+  if (async) {
+#define CGA_XS2_CASE(W, RB, EPL)                                                          \
+  if (weighted == W && row_bits == RB && epl == EPL)                                      \
+    return XsKernelChoice<ValT>{xs2_kernel<ValT, W, RB, EPL>, kXs2Threads,                \
+                                2 * (static_cast<int>(sizeof(double)) << RB)};
+    CGA_XS2_CASE(false, 12, 8)
+    CGA_XS2_CASE(false, 13, 8)
+    CGA_XS2_CASE(true, 12, 8)
+    CGA_XS2_CASE(true, 13, 8)
+#undef CGA_XS2_CASE
+    throw Failure(CUGRAPH_UNKNOWN_ERROR, "internal: no xs2_kernel for this tile layout");
+  }
 #define CGA_XS_CASE(W, RB, EPL, TH, WPE)                                                  \
   if (weighted == W && row_bits == RB && epl == EPL && threads == TH)                     \
     return XsKernelChoice<ValT>{xs_kernel<ValT, W, TH, RB, EPL, WPE>, TH,                 \
@@ -1772,6 +2258,7 @@ struct PullPlan {
   int xs_n_win{1}, xs_slice_shift{7}, xs_row_bits{12};
   int xs_epl{kXsEntriesPerLane};  // entries a lane of xs_kernel keeps in flight per pass
   int xs_threads{kThreads};       // threads of an xs_kernel workgroup (xs_threads_for)
+  bool xs_async{false};           // xs2_kernel: two accumulator banks, no item barriers
   DevBuf xs_ent, xs_w, xs_unit_off, xs_tile_row, xs_rec[2], xs_pbase, xs_fin_items;
   DevBuf hub_items;         // HubItem[n_hub_items]
   DevBuf hub_row_item_off;  // int64[counts[0] + 1]
@@ -1886,8 +2373,6 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   if (te_env) tile_edges = std::atoll(te_env);
   char const* sh_env  = std::getenv("CUGRAPH_AMD_XS_SLICE_SHIFT");
   int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
-  // 13 / 14 (512- / 1024-thread workgroups, 64 / 128 KiB of accumulators, tiles of up to 8192 /
-  // 16384 rows) were measured at scale 26: 3.8 / 7.0 ms against 2.3 ms for 12 -- kept at 12
   // Rows per tile: as many as the entry format allows.  An entry keeps 32 - row_bits bits of its
   // source position, the rest is implied by its window, and a record carries 59 window starts (up
   // to 16 windows they live in scalar registers, beyond that an entry's window is found by binary
@@ -1907,7 +2392,15 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   bool wide = g.weights == nullptr && sizeof(ValT) == 4 && row_bits >= 13 && (wide_env ? std::atoi(wide_env) != 0 : kXsWideDefault);
   if (wide && !rb_env) row_bits = 13;
   wide = wide && row_bits == 13;
-  int const threads = xs_threads_for(row_bits, wide);
+  // xs2_kernel (two banks of accumulators in one 1024-thread workgroup, items without barriers):
+  // tiles of at most 8192 rows.  CUGRAPH_AMD_XS_ASYNC=0/1.
+  char const* async_env = std::getenv("CUGRAPH_AMD_XS_ASYNC");
+  bool const async      = async_env ? std::atoi(async_env) != 0 : kXsAsyncDefault;
+  if (async) {
+    wide = false;
+    if (row_bits > 13) row_bits = 13;
+  }
+  int const threads = async ? kXs2Threads : xs_threads_for(row_bits, wide);
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,
@@ -2047,7 +2540,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int64_t const phase_min = pm_env ? std::atoll(pm_env) : (int64_t(1) << 18);  // entries per unit
   // (only for 16384-row tiles, the layout the parts were measured and run at full size with: graphs
   // whose source space needs 4096- or 8192-row tiles keep whole-unit items)
-  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows && (row_bits == kXsRowBitsMax || wide))
+  int const n_parts = (w0 == 0 && part_windows > 0 && n_win > part_windows && (row_bits == kXsRowBitsMax || wide || (async && row_bits == 13)))
                         ? (n_win + part_windows - 1) / part_windows : 1;
   std::vector<XsItem> h_items[2];
   std::vector<std::vector<XsItem>> part_items(n_parts);  // region 0 of phased tiles, by part
@@ -2058,6 +2551,17 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     int64_t const per_unit = entries_all_slices / kXsSlices;
     return static_cast<int32_t>(std::min<int64_t>(15, std::max<int64_t>(1, (per_unit + piece_entries / 2) / piece_entries)));
   };
+  // timing aid (results are then wrong): CUGRAPH_AMD_XS_ONLY_TILES=lo:hi keeps the work items of
+  // tiles lo <= t < hi only; the tile list (rows, entries) goes to stderr
+  int only_lo = 0, only_hi = n_tiles;
+  if (char const* ot = std::getenv("CUGRAPH_AMD_XS_ONLY_TILES")) {
+    std::sscanf(ot, "%d:%d", &only_lo, &only_hi);
+    for (int t = 0; t < n_tiles; ++t) {
+      int64_t const u0 = static_cast<int64_t>(t) * kXsSlices * n_win, u1 = static_cast<int64_t>(t + 1) * kXsSlices * n_win;
+      if (t < 12 || t % 50 == 0 || t == n_tiles - 1)
+        std::fprintf(stderr, "xs tile %d rows %d entries %lld\n", t, h_row[t + 1] - h_row[t], (long long)(h_uoff[u1] - h_uoff[u0]));
+    }
+  }
   for (int t = 0; t < n_tiles; ++t) {
     // entries of the tile per window, over its eight units
     auto count = [&](int lo, int hi) {
@@ -2111,6 +2615,13 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     whole.swap(h_items[0]);
     for (auto const& pi : part_items) h_items[0].insert(h_items[0].end(), pi.begin(), pi.end());
     h_items[0].insert(h_items[0].end(), whole.begin(), whole.end());
+    if (only_lo > 0 || only_hi < n_tiles) {
+      std::vector<XsItem> kept;
+      for (auto const& it : h_items[0])
+        if (it.tile >= only_lo && it.tile < only_hi) kept.push_back(it);
+      h_items[0].swap(kept);
+      std::fprintf(stderr, "xs only tiles [%d, %d) of %d: %zu items\n", only_lo, only_hi, n_tiles, h_items[0].size());
+    }
   }
   h_pbase[n_tiles] = plen;
   if (n_tiles >= (1 << 24) || h_items[0].size() + h_items[1].size() >= 0x7fffffffu / kXsSlices) return;
@@ -2145,6 +2656,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_row_bits  = row_bits;
   plan.xs_epl       = epl;
   plan.xs_threads   = threads;
+  plan.xs_async     = async;
 }
 
 template <typename OffT>
@@ -2320,7 +2832,10 @@ PullPlan& get_plan(Handle const& h, Graph& g)
       if (p->compact && p->xs_on && p->xs_row_first == 0 && std::getenv("CUGRAPH_AMD_KEEP_SLOT_COPY") == nullptr) {
         // keep the slot numbers of the edges below the XS rows only (see PullPlan::compact_tail)
         Graph& c = *p->compact;
-        int64_t const tail_first = p->xs_n_edges;  // XS rows are the first rows: their edges the first edges
+        // (XS rows are the first rows, their edges the first edges.)  The copy starts at a multiple
+        // of 4 edges: the biased base pointer below stays 16-byte aligned, and a reader that aligns
+        // a column start DOWN to 4 entries (column_partial) still lands inside the buffer.
+        int64_t const tail_first = p->xs_n_edges & ~int64_t(3);
         int64_t const n_tail     = c.num_edges - tail_first;
         DevBuf tail(static_cast<size_t>(n_tail + 8) * sizeof(int32_t));
         CGA_HIP(hipMemsetAsync(tail.p, 0, tail.bytes, stream));
@@ -2514,7 +3029,7 @@ int session_geometry(Session& s, PullPlan& plan)
   if (s.xs_on) {
     // the kernel instantiation for this plan's tiles, and as many workgroups as are resident at
     // once (LDS- and register-bound: asked of the runtime), capped by the work items there are
-    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl, plan.xs_threads);
+    XsKernelChoice<ValT> const ch = xs_pick<ValT>(s.cg->weights != nullptr, plan.xs_row_bits, plan.xs_epl, plan.xs_threads, plan.xs_async);
     CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(ch.kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ch.lds));
     int per_cu = 0, n_cu = 0;
@@ -2891,7 +3406,12 @@ void enqueue_iteration(Session& s, hipEvent_t ev_kernel_begin, hipEvent_t ev_ker
     auto kern = reinterpret_cast<void (*)(XsLaunch<ValT>)>(s.xs_kernel_fn);
     hipLaunchKernelGGL(kern, dim3(s.n_xs_blocks), dim3(s.xs_threads), s.xs_lds_bytes, stream, xl);
 #ifdef CGA_XS_PHASE_PROF
-    if (s.enqueued >= 3 && s.enqueued < 6) hipLaunchKernelGGL(xs_phase_dump_kernel, dim3(1), dim3(1), 0, stream);
+    if (s.enqueued >= 3 && s.enqueued < 6) {
+      if (plan.xs_async)
+        hipLaunchKernelGGL(xs2_phase_dump_kernel, dim3(1), dim3(1), 0, stream);
+      else
+        hipLaunchKernelGGL(xs_phase_dump_kernel, dim3(1), dim3(1), 0, stream);
+    }
 #endif
 #ifdef CGA_TIMING_AIDS
     if (a.xs.profile && s.enqueued == 3)
@@ -3041,6 +3561,7 @@ void session_status(Session& s, size_t* iters, bool* stopped, double* delta, dou
   if (iters) *iters = static_cast<size_t>(c.iters);
   // the stop flag is raised by the first kernel enqueued AFTER the converging iteration; when
   // nothing was enqueued after it the scalars still tell
+  CGA_EXPECTS((c.done & 2) == 0, CUGRAPH_UNKNOWN_ERROR, "internal: xs2_kernel gave up waiting on a work item");
   bool st = c.done != 0 || (c.iters > 0 && sc[1] < s.epsilon);
   if (stopped) *stopped = st;
   if (delta) *delta = sc[1];

@@ -6,4 +6,4 @@ python3 -c "
 import json
 d=json.load(open('gpurun_out/${tag}.json'))
 print('%-28s ms/step %.4f  xs_kernel %.4f'%('$tag', d['ms_per_step'], d['roofline']['kernel_ms_avg']))"
-grep -h XSPHASE gpurun_out/${tag}.err | tail -1
+grep -h "XS2\?PHASE" gpurun_out/${tag}.err | tail -1
