@@ -102,6 +102,8 @@ SIGNATURES = {
     "cugraph_amd_edgelist_source_weight_sums": (_int, [_vp, _vp, _vp, _vp, _vpp]),
     "cugraph_amd_edgelist_source_weight_sums_noalloc": (_int, [_vp, _vp, _vp, _vp, _vp, _vpp]),
     "cugraph_amd_partition_degree_order": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vpp]),
+    "cugraph_amd_partition_group_edges": (_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64), _sz, _vp, _vp, _vp,
+                                                 ctypes.POINTER(_i64), _vpp]),
     "cugraph_amd_graph_info": (_int, [_vp, ctypes.POINTER(_i64), _vpp]),
     "cugraph_amd_graph_get_compressed": (_int, [_vp, _vpp, _vpp, _vpp, _vpp, _vpp]),
     "cugraph_amd_graph_source_weight_sums": (_int, [_vp, _vp, _vp, _vpp]),

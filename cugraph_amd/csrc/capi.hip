@@ -723,6 +723,37 @@ cugraph_error_code_t cugraph_amd_partition_degree_order(
   });
 }
 
+cugraph_error_code_t cugraph_amd_partition_group_edges(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst, const cugraph_type_erased_device_array_view_t* weights,
+  const int64_t* bounds, size_t num_ranks, cugraph_type_erased_device_array_view_t* src_out,
+  cugraph_type_erased_device_array_view_t* dst_out, cugraph_type_erased_device_array_view_t* weights_out,
+  int64_t* counts, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto const* s = as<ArrayView>(src);
+    auto const* d = as<ArrayView>(dst);
+    auto const* w = as<ArrayView>(weights);
+    auto* so      = as<ArrayView>(src_out);
+    auto* dd      = as<ArrayView>(dst_out);
+    auto* wo      = as<ArrayView>(weights_out);
+    CGA_EXPECTS(s && d && so && dd && bounds && counts, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(is_int_type(d->type) && s->type == d->type && so->type == d->type && dd->type == d->type,
+                CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "src / dst and their outputs must share one of INT32, INT64");
+    CGA_EXPECTS(s->size == d->size && so->size == d->size && dd->size == d->size, CUGRAPH_INVALID_INPUT,
+                "src, dst and their outputs must have one entry per edge");
+    CGA_EXPECTS((w == nullptr) == (wo == nullptr), CUGRAPH_INVALID_INPUT, "weights and weights_out go together");
+    CGA_EXPECTS(!w || (is_float_type(w->type) && wo->type == w->type && w->size == d->size && wo->size == d->size),
+                CUGRAPH_INVALID_INPUT, "weights must be FLOAT32/FLOAT64 with one entry per edge, in and out");
+    CGA_EXPECTS(num_ranks >= 1 && num_ranks <= 256, CUGRAPH_INVALID_INPUT, "1 .. 256 ranks");
+    for (size_t r = 0; r < num_ranks; ++r)
+      CGA_EXPECTS(bounds[r] <= bounds[r + 1], CUGRAPH_INVALID_INPUT, "bounds must ascend");
+    partition_group_edges(as<Handle>(handle)->stream, *s, *d, w, bounds, static_cast<int>(num_ranks), so->data,
+                          dd->data, wo ? wo->data : nullptr, counts);
+  });
+}
+
 cugraph_error_code_t cugraph_amd_graph_info(const cugraph_graph_t* graph, int64_t info[8],
                                             cugraph_error_t** error)
 {

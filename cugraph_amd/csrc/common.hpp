@@ -311,6 +311,9 @@ void renumber_edgelist(Handle const& h, Graph& g, ArrayView const* vertices, Arr
 
 void partition_degree_order(hipStream_t stream, ArrayView const& dst, int64_t first, int64_t count,
                             int32_t* order_out, int32_t* rank_out);
+void partition_group_edges(hipStream_t stream, ArrayView const& src, ArrayView const& dst, ArrayView const* wgt,
+                           int64_t const* bounds, int n_ranks, void* src_out, void* dst_out, void* wgt_out,
+                           int64_t* counts_out);
 bool degrees_descending(hipStream_t stream, void const* offsets, bool off64, int64_t n);
 
 // edge_filter.hip: drop_self_loops / drop_multi_edges; the views are re-pointed at filtered copies

@@ -597,6 +597,166 @@ void partition_degree_order(hipStream_t stream, ArrayView const& dst, int64_t fi
   CGA_HIP(hipStreamSynchronize(stream));
 }
 
+// ---- edges grouped by the rank that owns their destination (the send side of the multi-GPU edge
+// shuffle; reference: shuffle_ext_vertex_pairs... / groupby_and_count over the 2D grid,
+// cpp/src/detail/shuffle_vertex_pairs.cu).  A stable multisplit by a key of at most 256 values: per
+// tile and owner counts -> one scan -> scatter with ballot-matched ranks, the same three steps as a
+// pass of degree_order's radix sort, moving the edge arrays themselves.
+namespace {
+constexpr int kGeMaxRanks = 256;
+
+template <typename IdT>
+__device__ inline unsigned int owner_of(IdT d, long long const* s_bounds, int n_ranks)
+{
+  // last rank whose first destination is <= d (bounds ascend; empty ranges share a bound)
+  int lo = 0, hi = n_ranks - 1;
+  while (lo < hi) {
+    int const mid = (lo + hi + 1) >> 1;
+    if (s_bounds[mid] <= static_cast<long long>(d)) lo = mid; else hi = mid - 1;
+  }
+  return static_cast<unsigned int>(lo);
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(kRsThreads) void group_count_kernel(IdT const* __restrict__ dst, int64_t n,
+                                                                 long long const* __restrict__ bounds, int n_ranks,
+                                                                 int64_t n_tiles, unsigned int* __restrict__ counts,
+                                                                 unsigned int* __restrict__ n_bad)
+{
+  __shared__ unsigned int cnt[kGeMaxRanks];
+  __shared__ long long s_bounds[kGeMaxRanks + 1];
+  int const lane = threadIdx.x & 63;
+  unsigned long long const below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  cnt[threadIdx.x] = 0u;
+  for (int k = threadIdx.x; k <= n_ranks; k += kRsThreads) s_bounds[k] = bounds[k];
+  __syncthreads();
+  int64_t const base = blockIdx.x * (int64_t)kRsTile;
+  unsigned int bad   = 0u;
+  for (int r = 0; r < kRsRounds; ++r) {
+    int64_t const i  = base + r * kRsThreads + threadIdx.x;
+    bool const valid = i < n;
+    IdT const d      = valid ? dst[i] : IdT(0);
+    bad += valid && (static_cast<long long>(d) < s_bounds[0] || static_cast<long long>(d) >= s_bounds[n_ranks]);
+    unsigned int const o       = owner_of(d, s_bounds, n_ranks);
+    unsigned long long const m = same_digit_lanes(o, valid);
+    if (valid && (m & below) == 0ull) atomicAdd(&cnt[o], static_cast<unsigned int>(__popcll(m)));
+  }
+  if (bad) atomicAdd(n_bad, bad);
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < n_ranks) counts[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+template <typename IdT, typename WgtT>
+__global__ __launch_bounds__(kRsThreads) void group_scatter_kernel(
+  IdT const* __restrict__ src, IdT const* __restrict__ dst, WgtT const* __restrict__ wgt, int64_t n,
+  long long const* __restrict__ bounds, int n_ranks, int64_t n_tiles, int64_t const* __restrict__ first_pos,
+  IdT* __restrict__ src_out, IdT* __restrict__ dst_out, WgtT* __restrict__ wgt_out)
+{
+  __shared__ int64_t run[kGeMaxRanks];  // next output position of every owner
+  __shared__ int64_t wave_pos[kRsThreads / 64][kGeMaxRanks];
+  __shared__ unsigned int wave_cnt[kRsThreads / 64][kGeMaxRanks];
+  __shared__ long long s_bounds[kGeMaxRanks + 1];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long const below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  run[threadIdx.x] = static_cast<int>(threadIdx.x) < n_ranks ? first_pos[threadIdx.x * n_tiles + blockIdx.x] : 0;
+  for (int k = threadIdx.x; k <= n_ranks; k += kRsThreads) s_bounds[k] = bounds[k];
+  int64_t const base = blockIdx.x * (int64_t)kRsTile;
+  for (int r = 0; r < kRsRounds; ++r) {
+    int64_t const i  = base + r * kRsThreads + threadIdx.x;  // round-major: input order
+    bool const valid = i < n;
+#pragma unroll
+    for (int w = 0; w < kRsThreads / 64; ++w) wave_cnt[w][threadIdx.x] = 0u;
+    __syncthreads();
+    IdT const d                = valid ? dst[i] : IdT(0);
+    unsigned int const o       = owner_of(d, s_bounds, n_ranks);
+    unsigned long long const m = same_digit_lanes(o, valid);
+    int const rank             = __popcll(m & below);
+    if (valid && rank == 0) wave_cnt[wave][o] = static_cast<unsigned int>(__popcll(m));
+    __syncthreads();
+    {  // thread = owner: where each wave's edges of this owner start
+      int64_t p = run[threadIdx.x];
+#pragma unroll
+      for (int w = 0; w < kRsThreads / 64; ++w) {
+        wave_pos[w][threadIdx.x] = p;
+        p += wave_cnt[w][threadIdx.x];
+      }
+      run[threadIdx.x] = p;
+    }
+    __syncthreads();
+    if (valid) {
+      int64_t const p = wave_pos[wave][o] + rank;
+      src_out[p]      = src[i];
+      dst_out[p]      = d;
+      if (wgt) wgt_out[p] = wgt[i];
+    }
+  }
+}
+
+__global__ void owner_totals_kernel(int64_t const* __restrict__ first_pos, int64_t n_tiles, int n_ranks, int64_t n,
+                                    long long* __restrict__ totals)
+{
+  int const o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o < n_ranks) {
+    int64_t const beg = first_pos[static_cast<int64_t>(o) * n_tiles];
+    int64_t const end = o + 1 < n_ranks ? first_pos[static_cast<int64_t>(o + 1) * n_tiles] : n;
+    totals[o]         = end - beg;
+  }
+}
+}  // namespace
+
+// src / dst (same integer type) and optional weights of one rank's share of the edge list ->
+// the same edges grouped by the owner of their destination, input order kept inside a group;
+// counts_out[r] = edges that go to rank r.  bounds: host, n_ranks + 1 ascending destination bounds.
+void partition_group_edges(hipStream_t stream, ArrayView const& src, ArrayView const& dst, ArrayView const* wgt,
+                           int64_t const* bounds, int n_ranks, void* src_out, void* dst_out, void* wgt_out,
+                           int64_t* counts_out)
+{
+  CGA_EXPECTS(n_ranks >= 1 && n_ranks <= kGeMaxRanks, CUGRAPH_INVALID_INPUT, "1 .. 256 ranks");
+  int64_t const n = static_cast<int64_t>(dst.size);
+  for (int r = 0; r < n_ranks; ++r) counts_out[r] = 0;
+  if (n == 0) return;
+  int64_t const n_tiles = (n + kRsTile - 1) / kRsTile;
+  size_t const n_counts = static_cast<size_t>(n_tiles) * n_ranks;
+  DevBuf d_bounds(static_cast<size_t>(n_ranks + 1) * 8), counts(n_counts * 4), pos((n_counts + 1) * 8), bad(4),
+    totals(static_cast<size_t>(n_ranks) * 8);
+  std::vector<long long> h_bounds(bounds, bounds + n_ranks + 1);
+  CGA_HIP(hipMemcpyAsync(d_bounds.p, h_bounds.data(), d_bounds.bytes, hipMemcpyHostToDevice, stream));
+  CGA_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+  auto run = [&](auto id_tag) {
+    using IdT = decltype(id_tag);
+    hipLaunchKernelGGL((group_count_kernel<IdT>), dim3(static_cast<unsigned>(n_tiles)), dim3(kRsThreads), 0, stream,
+                       static_cast<IdT const*>(dst.data), n, d_bounds.as<long long>(), n_ranks, n_tiles,
+                       counts.as<unsigned int>(), bad.as<unsigned int>());
+    exclusive_scan_u32_to_i64(stream, counts.as<unsigned int>(), static_cast<int64_t>(n_counts), pos.as<int64_t>());
+    auto scatter = [&](auto w_tag) {
+      using WgtT = decltype(w_tag);
+      hipLaunchKernelGGL((group_scatter_kernel<IdT, WgtT>), dim3(static_cast<unsigned>(n_tiles)), dim3(kRsThreads), 0,
+                         stream, static_cast<IdT const*>(src.data), static_cast<IdT const*>(dst.data),
+                         wgt ? static_cast<WgtT const*>(wgt->data) : nullptr, n, d_bounds.as<long long>(), n_ranks,
+                         n_tiles, pos.as<int64_t>(), static_cast<IdT*>(src_out), static_cast<IdT*>(dst_out),
+                         static_cast<WgtT*>(wgt_out));
+    };
+    if (wgt && wgt->type == FLOAT64)
+      scatter(double{});
+    else
+      scatter(float{});
+  };
+  if (dst.type == INT64)
+    run(int64_t{});
+  else
+    run(int32_t{});
+  hipLaunchKernelGGL(owner_totals_kernel, dim3(1), dim3(kGeMaxRanks), 0, stream, pos.as<int64_t>(), n_tiles, n_ranks, n,
+                     totals.as<long long>());
+  CGA_HIP(hipGetLastError());
+  unsigned int h_bad = 0;
+  std::vector<long long> h_tot(n_ranks);
+  CGA_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipMemcpyAsync(h_tot.data(), totals.p, totals.bytes, hipMemcpyDeviceToHost, stream));
+  CGA_HIP(hipStreamSynchronize(stream));
+  CGA_EXPECTS(h_bad == 0, CUGRAPH_INVALID_INPUT, "destination ids outside the bounds of the partition");
+  for (int r = 0; r < n_ranks; ++r) counts_out[r] = h_tot[r];
+}
+
 // true when the majors of a compressed graph are in non-increasing degree order
 bool degrees_descending(hipStream_t stream, void const* offsets, bool off64, int64_t n)
 {

@@ -129,6 +129,20 @@ def _dist():
     return dist
 
 
+def exchange_mode(world):
+    """How the source values travel each iteration.  "personal" (the default from 2 ranks on): every
+    rank numbers its slots privately -- its own sources, then exactly the foreign ones its edges read
+    -- and one all-to-all delivers those; at 8 ranks a rank reads 47 % of the others' sources, so it
+    receives half the bytes of an all-gather and gathers from a vector half as long (one rank of 8 at
+    scale 28: 160 instead of 350 MB, 1.44 instead of 1.52 ms of compute; profiles/r3_mg_table.md).
+    "gather": the all-gather of every rank's chunk (CUGRAPH_AMD_MG_EXCHANGE=gather; implied by two
+    regions, CUGRAPH_AMD_MG_REGIONS, which only the all-gather layout has)."""
+    env = os.environ.get("CUGRAPH_AMD_MG_EXCHANGE")
+    if env in ("personal", "gather"):
+        return env
+    return "gather" if os.environ.get("CUGRAPH_AMD_MG_REGIONS", "0") in ("1", "auto") else "personal"
+
+
 def _gather_through_host(x_full, chunk, rank, world, group):
     """gloo with device tensors (ranks of a rehearsal sharing one GPU): its flat in-place form
     never completes there, so the chunks travel as host copies."""
@@ -203,33 +217,49 @@ def all_gather_region_async(region, sub_chunk, rank, world, group=None):
         return _Done()
 
 
-def shuffle_edges_to_owner(src, dst, wgt, bounds, world, group=None):
-    """Route every edge to the rank that owns its destination (one all-to-all per array).
+def shuffle_edges_to_owner(engine, src, dst, wgt, bounds, world, group=None):
+    """Route every edge to the rank that owns its destination: the engine groups this rank's share by
+    owner (the library's stable multisplit, cugraph_amd_partition_group_edges: one counting pass, one
+    scan, one scatter of the edge arrays themselves -- round 2 did this with a bucketize, one
+    torch.nonzero per owner and three E-sized gathers), then one all-to-all per array.
     bounds: the P+1 bounds of the destination ranges."""
     import torch
 
-    dist = _dist()
-    inner = torch.as_tensor(bounds[1:-1], dtype=torch.int64, device=dst.device)
-    owner = torch.bucketize(dst.to(torch.int64), inner, right=True)
-    # edges grouped by owner, input order kept: one compaction per owner (a stable sort of E keys
-    # for a handful of distinct values is the slower way to say the same)
-    if world <= 64:
-        order = torch.cat([torch.nonzero(owner == p).flatten() for p in range(world)])
-    else:
-        order = torch.argsort(owner, stable=True)
-    send_counts = torch.bincount(owner, minlength=world)
+    src, dst, wgt, in_split = engine.group_edges(src, dst, wgt, bounds)
+    send_counts = torch.tensor(in_split, dtype=torch.int64, device=dst.device)
     recv_counts = torch.empty_like(send_counts)
     all_to_all_single(recv_counts, send_counts, group=group)
-    in_split = [int(c) for c in send_counts.tolist()]
     out_split = [int(c) for c in recv_counts.tolist()]
 
     def route(a):
-        a = a[order].contiguous()
         out = torch.empty(sum(out_split), dtype=a.dtype, device=a.device)
         all_to_all_single(out, a, out_split, in_split, group)
         return out
 
     return route(src), route(dst), (None if wgt is None else route(wgt))
+
+
+def reduce_to_owners(full, bounds, rank, world, group=None):
+    """Sum over the ranks of a V-length vector, every rank keeping only ITS range [bounds[rank],
+    bounds[rank + 1]): one reduce-scatter over ranges padded to the longest (RCCL), where round 2
+    all-reduced the whole vector to every rank -- 1/P of the bytes received.  Backends without a
+    reduce-scatter (gloo) fall back to the all-reduce."""
+    import torch
+
+    dist = _dist()
+    first, last = bounds[rank], bounds[rank + 1]
+    if world == 1:
+        return full[first:last].clone()
+    if dist.get_backend(group) != "nccl":
+        all_reduce(full, group)
+        return full[first:last].clone()
+    longest = max(max(b - a for a, b in zip(bounds, bounds[1:])), 1)
+    padded = torch.zeros(world * longest, dtype=full.dtype, device=full.device)
+    for r in range(world):
+        padded[r * longest:r * longest + bounds[r + 1] - bounds[r]] = full[bounds[r]:bounds[r + 1]]
+    mine = torch.empty(longest, dtype=full.dtype, device=full.device)
+    dist.reduce_scatter_tensor(mine, padded, group=group)
+    return mine[:last - first].clone()
 
 
 class HipEngine:
@@ -263,6 +293,35 @@ class HipEngine:
             for v in views:
                 free_view(v)
         return order, rank
+
+    def group_edges(self, src, dst, wgt, bounds):
+        """(src, dst, wgt, counts): the edges grouped by the owner of their destination, input order kept
+        inside a group; counts[r] = edges for rank r (cugraph_amd_partition_group_edges)."""
+        import ctypes
+
+        import torch
+
+        from . import _capi
+        from .pylibcugraph.utils import create_view_from_py_obj, free_view
+
+        world = len(bounds) - 1
+        src, dst = src.contiguous(), dst.contiguous()
+        wgt = None if wgt is None else wgt.contiguous()
+        outs = [torch.empty_like(src), torch.empty_like(dst), None if wgt is None else torch.empty_like(wgt)]
+        views = [None if t is None else create_view_from_py_obj(t) for t in (src, dst, wgt, *outs)]
+        c_bounds = (ctypes.c_int64 * (world + 1))(*[int(b) for b in bounds])
+        c_counts = (ctypes.c_int64 * world)()
+        err = ctypes.c_void_p()
+        try:
+            code = _capi.load().cugraph_amd_partition_group_edges(
+                self.handle.c_resource_handle_ptr, views[0], views[1], views[2], c_bounds, world, views[3],
+                views[4], views[5], c_counts, ctypes.byref(err))
+            _capi.check(code, err, "cugraph_amd_partition_group_edges")
+        finally:
+            for v in views:
+                if v is not None:
+                    free_view(v)
+        return outs[0], outs[1], outs[2], [int(c) for c in c_counts]
 
     def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
                          x_pos=None, hot_slots=0):
@@ -356,23 +415,39 @@ class MGPagerank:
         world = dist.get_world_size(group) if world is None else world
         self = cls(engine, num_vertices, rank, world, group)
         t0 = time.perf_counter()
+        marks = [("start", t0)]
+
+        def mark(name):  # CUGRAPH_AMD_MG_PROFILE=1: where the set-up time goes (synchronises at every mark)
+            if os.environ.get("CUGRAPH_AMD_MG_PROFILE") == "1":
+                if engine.device == "cuda":
+                    torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
+
         self.vertex_dtype = src.dtype
         self.value_dtype = torch.float32 if wgt is None else wgt.dtype
         if os.environ.get("CUGRAPH_AMD_MG_PARTITION", "edges") != "equal":
             self.set_bounds(edge_balanced_bounds(dst, self.num_vertices, world, group))
+        mark("bounds")
         if world > 1:
-            src, dst, wgt = shuffle_edges_to_owner(src, dst, wgt, self.bounds, world, group)
-        # out-edge counts and out-weight sums per source, over all ranks
+            src, dst, wgt = shuffle_edges_to_owner(engine, src, dst, wgt, self.bounds, world, group)
+        mark("shuffle")
+        # out-edge counts and out-weight sums per source: every rank tallies the sources of ITS edges
+        # over the whole vertex range and the owners receive the sums of their own vertices
         counts = engine.source_weight_sums(src, None, self.num_vertices)
-        sums = counts if wgt is None else engine.source_weight_sums(src, wgt, self.num_vertices)
-        if world > 1:
-            all_reduce(counts, group)
-            if wgt is not None:
-                all_reduce(sums, group)
+        own_sums = None
+        if wgt is not None:
+            own_sums = reduce_to_owners(engine.source_weight_sums(src, wgt, self.num_vertices), self.bounds, rank,
+                                        world, group)
+        own_counts = reduce_to_owners(counts, self.bounds, rank, world, group)
+        del counts
+        if own_sums is None:
+            own_sums = own_counts
+        mark("source sums")
         # rows: descending in-degree inside the owned range
         self.order, self.rank_local = engine.degree_order(dst, self.first, self.last)
-        own_counts = counts[self.first:self.last]
+        mark("degree order")
         self._sources_first_among_rows_without_in_edges(dst, own_counts)
+        mark("sources first")
 
         def assign_slots():
             """slots: this rank's vertices with out-edges, numbered in row order (hottest first);
@@ -413,21 +488,31 @@ class MGPagerank:
             mine = torch.full((self.last - self.first,), -1, dtype=torch.int32, device=src.device)
             mine[order] = x_pos
             index_at_owner = all_gather_ragged(mine, self.lengths, rank, world, group, fill=-1)
+            # the sources this rank's edges read, as a mark per vertex (V-sized; round 2 sorted the
+            # E-sized key list with torch.unique): the marked foreign vertices, numbered owner by
+            # owner in the owner's row order, are the slots behind this rank's own sources
+            read = torch.zeros(self.num_vertices, dtype=torch.bool, device=src.device)
+            read[src] = True
+            read[self.first:self.last] = False
+            ids = torch.nonzero(read).reshape(-1)  # ascending vertex id: owner-major
+            del read
             inner = torch.as_tensor(self.bounds[1:-1], dtype=torch.int64, device=src.device)
-            owner = torch.bucketize(src.to(torch.int64), inner, right=True)
-            j_src = index_at_owner[src.long()].long()
-            key = (owner << 32) + j_src
-            foreign = owner != rank
-            uniq = torch.unique(key[foreign])  # ascending: owner-major, then the owner's row order
-            pos = torch.searchsorted(uniq, key) if uniq.numel() else torch.zeros_like(key)
-            slot = torch.where(foreign, n_own + pos, j_src)
+            owner = torch.bucketize(ids, inner, right=True)
+            j_ids = index_at_owner[ids].long()
+            key = (owner << 32) + j_ids  # V-sized at most: the owner's row order inside each owner
+            uniq, perm = torch.sort(key)
+            slot_of_vertex = torch.full((self.num_vertices,), -1, dtype=torch.int64, device=src.device)
+            slot_of_vertex[ids[perm]] = n_own + torch.arange(ids.numel(), dtype=torch.int64, device=src.device)
+            slot_of_vertex[self.first:self.last] = index_at_owner[self.first:self.last].long()
+            slot = slot_of_vertex[src]
             return x_pos, slot, n_own, uniq
 
-        personal = world > 1 and os.environ.get("CUGRAPH_AMD_MG_EXCHANGE") == "personal"
+        personal = world > 1 and exchange_mode(world) == "personal"
         if personal:
             x_pos, src_slot, n_own, uniq = assign_private_slots()
         else:
             x_pos, slot_of, n_slots, hot_slots = assign_slots()
+        mark("slots")
         # rows of in-degree 1-3 in the order of their smallest source (decided for all ranks alike:
         # the slots are assigned again afterwards, which is a collective)
         n_edges_all = torch.tensor([src.numel()], dtype=torch.int64, device=src.device)
@@ -436,7 +521,7 @@ class MGPagerank:
         env = os.environ.get("CUGRAPH_AMD_RENUMBER_LOCALITY")
         if env == "1" or (env is None and int(n_edges_all.item()) >= (1 << 22)):
             rows = self.rank_local[(dst - self.first).long()].long()
-            self._order_low_degree_rows_by_source(src_slot if personal else slot_of[src.long()].long(), rows)
+            self._order_low_degree_rows_by_source(src_slot if personal else slot_of[src].long(), rows)
             del rows, x_pos
             # slots follow the rows, so that a rank still writes its values in row order
             if personal:
@@ -444,6 +529,7 @@ class MGPagerank:
             else:
                 del slot_of
                 x_pos, slot_of, n_slots, hot_slots = assign_slots()
+        mark("low rows by source + slots again")
         if personal:
             # every owner learns which of its sources each rank reads (counts, then the index lists)
             want = torch.bincount(uniq >> 32, minlength=world)
@@ -460,16 +546,22 @@ class MGPagerank:
             src = src_slot.to(self.vertex_dtype)
             del src_slot, uniq
         else:
-            src = slot_of[src.long()].to(self.vertex_dtype)
+            src = slot_of[src].to(self.vertex_dtype)
             del slot_of
-        dst = (self.rank_local[(dst - self.first).long()] + self.first).to(self.vertex_dtype)
+        dst = (self.rank_local[dst - self.first] + self.first).to(self.vertex_dtype)
         order = self.order.long()
+        mark("relabel")
         self.graph = engine.make_local_graph(src, dst, wgt, self.first, self.last, self.num_vertices,
                                              num_source_slots=n_slots, x_pos=x_pos, hot_slots=hot_slots)
         del src, dst, wgt, x_pos
-        self.out_w = sums[self.first:self.last][order].clone()  # internal (row) order
-        del sums, counts
+        self.out_w = own_sums[order].clone()  # internal (row) order
+        del own_sums, own_counts
+        mark("local graph")
         self.t_build = time.perf_counter() - t0
+        if len(marks) > 1:
+            import sys
+            print("MGPROF rank %d: " % rank + ", ".join("%s %.3f s" % (n, t - marks[i][1]) for i, (n, t) in enumerate(marks[1:])),
+                  file=sys.stderr, flush=True)
         return self
 
     def _sources_first_among_rows_without_in_edges(self, dst, own_counts):

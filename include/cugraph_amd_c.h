@@ -345,6 +345,21 @@ cugraph_error_code_t cugraph_amd_partition_degree_order(
   int64_t vertex_first, int64_t vertex_last, cugraph_type_erased_device_array_view_t* order,
   cugraph_type_erased_device_array_view_t* rank, cugraph_error_t** error);
 
+/* The send side of the multi-GPU edge shuffle: one rank's share of the edge list grouped by the rank
+ * that owns each edge's DESTINATION (rank r owns [bounds[r], bounds[r+1]); bounds: host array of
+ * num_ranks + 1 ascending ids), input order kept inside a group; counts[r] (host, num_ranks entries)
+ * = edges that go to rank r, i.e. the split sizes of the all-to-all that follows.  src / dst and
+ * their outputs: device views of one type (INT32 or INT64) and one length; weights / weights_out
+ * both NULL or both FLOAT32 / FLOAT64 views of that length.  Replaces, for this path, the
+ * reference's groupby_and_count + shuffle of an edge list over its 2D grid
+ * (cpp/src/detail/shuffle_vertex_pairs.cu; cpp/include/cugraph/utilities/shuffle_comm.cuh). */
+cugraph_error_code_t cugraph_amd_partition_group_edges(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst, const cugraph_type_erased_device_array_view_t* weights,
+  const int64_t* bounds, size_t num_ranks, cugraph_type_erased_device_array_view_t* src_out,
+  cugraph_type_erased_device_array_view_t* dst_out, cugraph_type_erased_device_array_view_t* weights_out,
+  int64_t* counts, cugraph_error_t** error);
+
 /* Shape of a graph: info[0]=num_vertices (local majors), [1]=num_edges, [2]=num_global_vertices,
  * [3]=vertex_first, [4]=store_transposed, [5]=offsets are int64, [6]=weighted, [7]=renumbered */
 cugraph_error_code_t cugraph_amd_graph_info(const cugraph_graph_t* graph, int64_t info[8],

@@ -125,6 +125,14 @@ class OracleEngine:
         rank[order] = np.arange(len(order), dtype=np.int32)
         return torch.from_numpy(order), torch.from_numpy(rank)
 
+    def group_edges(self, src, dst, wgt, bounds):
+        inner = np.asarray(bounds[1:-1], dtype=np.int64)
+        owner = np.searchsorted(inner, dst.numpy().astype(np.int64), side="right")
+        order = torch.from_numpy(np.argsort(owner, kind="stable"))
+        counts = np.bincount(owner, minlength=len(bounds) - 1)
+        return (src[order].contiguous(), dst[order].contiguous(), None if wgt is None else wgt[order].contiguous(),
+                [int(c) for c in counts])
+
     def make_local_graph(self, src, dst, wgt, first, last, num_global, num_source_slots=None,
                          x_pos=None, hot_slots=0):
         return _Graph(src, dst, wgt, first, last, num_global, num_source_slots, x_pos, hot_slots,

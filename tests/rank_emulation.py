@@ -16,7 +16,7 @@ def _count(ids, nv):
     return out
 
 
-def build_rank(handle, props, src, dst, nv, world, me, *, locality=None):
+def build_rank(handle, props, src, dst, nv, world, me, *, locality=None, private=False):
     """src, dst: the WHOLE edge list (device int32).  Returns a dict: engine, graph, first, last,
     order (row -> offset of the caller's id in the range), x_pos, slot_of (caller's id -> slot, all ranks),
     indeg, outdeg, n_slots, hot, regions, n_local_edges."""
@@ -89,8 +89,30 @@ def build_rank(handle, props, src, dst, nv, world, me, *, locality=None):
             rank_l[new_order] = torch.arange(last - first, dtype=torch.int32, device="cuda")
             my_x_pos = slots_of(me, outdeg[first:last][new_order] > 0)
             slot_of[first + new_order] = my_x_pos
-    g = eng.make_local_graph(slot_of[s_l.long()], rank_l[(d_l - first).long()] + first, None, first, last, nv,
+    n_own = n_foreign = 0
+    if private:
+        # the PERSONALISED exchange's numbering (mg.py: assign_private_slots): this rank's own sources
+        # first, in row order, then the sources of the other ranks that its edges read, owner by owner
+        # in the owner's row order -- the order of the shared slot numbers (one region), so: mark the
+        # shared slots read, number the marked ones
+        assert regions is None, "private slots have one region"
+        shared = slot_of[s_l.long()].long()
+        lo, hi = me * slot_chunk, (me + 1) * slot_chunk
+        read = torch.zeros(n_slots + 1, dtype=torch.int32, device="cuda")
+        read[shared] = 1
+        read[lo:hi] = 0
+        pos = torch.cumsum(read, 0, dtype=torch.int32) - read  # index among the foreign slots read
+        n_own = int((my_x_pos >= 0).sum())
+        n_foreign = int(read.sum())
+        own = (shared >= lo) & (shared < hi)
+        local_slots = torch.where(own, shared - lo, n_own + pos[shared].long()).to(torch.int32)
+        del shared, own, read, pos
+        my_x_pos = torch.where(my_x_pos >= 0, my_x_pos - lo, my_x_pos).to(torch.int32)
+        n_slots = max(n_own + n_foreign, 1)
+    else:
+        local_slots = slot_of[s_l.long()]
+    g = eng.make_local_graph(local_slots, rank_l[(d_l - first).long()] + first, None, first, last, nv,
                              num_source_slots=n_slots, x_pos=my_x_pos, hot_slots=hot)
     return dict(engine=eng, graph=g, first=first, last=last, order=orders[me], x_pos=my_x_pos, slot_of=slot_of,
                 indeg=indeg, outdeg=outdeg, n_slots=n_slots, hot=hot, regions=regions,
-                n_local_edges=int(s_l.numel()), local_src_slots=slot_of[s_l.long()])
+                n_local_edges=int(s_l.numel()), local_src_slots=local_slots, n_own=n_own, n_foreign=n_foreign)

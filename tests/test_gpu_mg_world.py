@@ -39,14 +39,20 @@ def test_driver_over_rccl_with_every_gpu_of_the_machine(mode, regions):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("regions", ["0", "1"])
+@pytest.mark.parametrize("layout", ["one-region", "two-regions", "personal"])
 @pytest.mark.parametrize("mode", ["unweighted", "weighted"])
-def test_driver_with_ranks_sharing_one_gpu_over_gloo(mode, regions, world):
+def test_driver_with_ranks_sharing_one_gpu_over_gloo(mode, layout, world):
+    """layout: the gathered vector as P chunks (one all-gather), as two regions (two all-gathers, phase 0 on
+    the hot one), or the PERSONALISED exchange -- private slot numbering per rank, one all-to-all of exactly
+    the values each rank's edges read, landing in the library-owned vector behind its own sources."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, CUGRAPH_AMD_MG_REGIONS=regions, CUGRAPH_AMD_TEST_SHARED_GPU="1",
+    env = dict(os.environ, CUGRAPH_AMD_MG_REGIONS="1" if layout == "two-regions" else "0", CUGRAPH_AMD_TEST_SHARED_GPU="1",
                CUGRAPH_AMD_XS_MIN_EDGES="65536", CUGRAPH_AMD_TEST_DUMP_AFTER="100")  # a stuck rank dumps its stack and exits
+    env.pop("CUGRAPH_AMD_MG_EXCHANGE", None)
+    if layout == "personal":
+        env["CUGRAPH_AMD_MG_EXCHANGE"] = "personal"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -55,3 +61,35 @@ def test_driver_with_ranks_sharing_one_gpu_over_gloo(mode, regions, world):
                        capture_output=True, text=True, timeout=170, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert r.stdout.count("iterations, max-abs") == world
+
+
+@pytest.mark.parametrize("id_dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_group_edges_by_owner_matches_a_stable_sort(world, weighted, id_dtype):
+    """cugraph_amd_partition_group_edges (the send side of the edge shuffle) against numpy's stable argsort by
+    owner, bit-exact: ragged bounds with an empty range, more edges than one tile of the multisplit."""
+    import numpy as np
+
+    from cugraph_amd import mg, pylibcugraph as plc
+
+    rng = np.random.default_rng(world * 7 + weighted)
+    nv, ne = 5000, 70001
+    cuts = np.sort(rng.integers(0, nv, size=world - 1)) if world > 1 else np.array([], dtype=np.int64)
+    if world > 2:
+        cuts[1] = cuts[0]  # an empty range
+    bounds = [0, *[int(c) for c in cuts], nv]
+    src = rng.integers(0, nv, size=ne)
+    dst = rng.integers(0, nv, size=ne)
+    wgt = rng.random(ne) if weighted else None
+    eng = mg.HipEngine(plc.ResourceHandle(), plc.GraphProperties(is_multigraph=True))
+    t = lambda a, dt: None if a is None else torch.from_numpy(a).to(dt).cuda()  # noqa: E731
+    g_src, g_dst, g_wgt, counts = eng.group_edges(t(src, id_dtype), t(dst, id_dtype), t(wgt, torch.float64), bounds)
+    owner = np.searchsorted(np.asarray(bounds[1:-1], dtype=np.int64), dst, side="right")
+    order = np.argsort(owner, kind="stable")
+    assert counts == np.bincount(owner, minlength=world).tolist()
+    assert np.array_equal(g_src.cpu().numpy(), src[order]) and np.array_equal(g_dst.cpu().numpy(), dst[order])
+    if weighted:
+        assert np.array_equal(g_wgt.cpu().numpy(), wgt[order])
+    with pytest.raises(ValueError):  # a destination outside the bounds
+        eng.group_edges(t(src, id_dtype), t(dst + nv, id_dtype), None, bounds)

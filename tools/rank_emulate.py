@@ -11,10 +11,11 @@ from rank_emulation import build_rank
 
 scale, world = int(sys.argv[1]), int(sys.argv[2])
 me = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+private = len(sys.argv) > 4 and sys.argv[4] == "private"  # the personalised exchange's slot numbering
 nv, ne = 1 << scale, 16 << scale
 h = plc.ResourceHandle(rank=me, comm_size=world)
 src, dst = generators.rmat(h, scale, ne, seed=42, scramble_vertex_ids=True)
-R = build_rank(h, plc.GraphProperties(is_multigraph=True), src, dst, nv, world, me)
+R = build_rank(h, plc.GraphProperties(is_multigraph=True), src, dst, nv, world, me, private=private)
 del src, dst
 first, last, n_slots, hot, regions = R["first"], R["last"], R["n_slots"], R["hot"], R["regions"]
 # how much of the gathered vector this rank's edges ever read (the case for a personalised exchange)
@@ -24,9 +25,13 @@ n_ref = int(ref.sum())
 mine = R["x_pos"][R["x_pos"] >= 0].long()
 n_ref_remote = n_ref - int(ref[mine].sum())
 n_own = int(mine.numel())
-print(f"rank {me} of {world} reads {n_ref} of {n_slots} slots ({100.0 * n_ref / n_slots:.1f} %); "
-      f"{n_ref_remote} of the {n_slots - n_own} slots of other ranks ({100.0 * n_ref_remote / max(n_slots - n_own, 1):.1f} %)",
-      flush=True)
+if private:
+    print(f"rank {me} of {world}, private slots: {R['n_own']} own + {R['n_foreign']} foreign sources read = {n_slots} slots; "
+          f"received per iteration {R['n_foreign'] * 4 / 1e6:.1f} MB", flush=True)
+else:
+  print(f"rank {me} of {world} reads {n_ref} of {n_slots} slots ({100.0 * n_ref / n_slots:.1f} %); "
+        f"{n_ref_remote} of the {n_slots - n_own} slots of other ranks ({100.0 * n_ref_remote / max(n_slots - n_own, 1):.1f} %)",
+        flush=True)
 del ref
 ids = torch.arange(first, last, dtype=torch.int32, device="cuda")
 sums = R["outdeg"][first:last][R["order"]].to(torch.float32)
