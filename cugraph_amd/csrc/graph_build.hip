@@ -265,11 +265,12 @@ __global__ void scatter_kernel(int32_t const* __restrict__ majors,
 
 // scatter for long columns (see hist_lds_kernel): a workgroup counts its span in LDS, reserves one
 // run per major it met with a single global atomic, then hands out the positions of the run with
-// LDS atomics.  32-bit offsets only (the positions live in LDS words).
-template <typename KeyT>
+// LDS atomics.  The positions live in 32-bit LDS words: relative to the first column of the window
+// (64-bit offsets: a window whose columns hold 2^32 edges or more goes the global way).
+template <typename OffT, typename KeyT>
 __global__ __launch_bounds__(1024) void scatter_lds_kernel(int32_t const* __restrict__ majors,
                                                            int32_t const* __restrict__ minors, int64_t n,
-                                                           int32_t const* __restrict__ offsets,
+                                                           OffT const* __restrict__ offsets, int64_t n_major,
                                                            unsigned int* __restrict__ cursor,
                                                            KeyT* __restrict__ keys)
 {
@@ -288,24 +289,27 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(int32_t const* __rest
   // through global atomics
   int32_t first;
   (void)span_window(majors, beg, end, &first);
+  // columns [first, w_end) are the window; its first edge is the base of the LDS positions
+  int64_t const w_end = static_cast<int64_t>(first) + kLdsMajors < n_major ? static_cast<int64_t>(first) + kLdsMajors : n_major;
+  int64_t const base  = static_cast<int64_t>(offsets[first]);
+  unsigned int const in_lds = static_cast<int64_t>(offsets[w_end]) - base < 0xFFFFFFFFLL ? static_cast<unsigned int>(kLdsMajors) : 0u;
   for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) lds_pos[k] = 0u;
   __syncthreads();
   for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
     unsigned int const d = static_cast<unsigned int>(majors[e] - first);
-    if (d < static_cast<unsigned int>(kLdsMajors)) atomicAdd(&lds_pos[d], 1u);
+    if (d < in_lds) atomicAdd(&lds_pos[d], 1u);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < kLdsMajors; k += blockDim.x) {
     unsigned int const c = lds_pos[k];
-    if (c) lds_pos[k] = static_cast<unsigned int>(offsets[first + k]) + atomicAdd(&cursor[first + k], c);
+    if (c) lds_pos[k] = static_cast<unsigned int>(static_cast<int64_t>(offsets[first + k]) - base) + atomicAdd(&cursor[first + k], c);
   }
   __syncthreads();
   for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
     int32_t const m      = majors[e];
     unsigned int const d = static_cast<unsigned int>(m - first);
-    unsigned int const pos = d < static_cast<unsigned int>(kLdsMajors)
-                               ? atomicAdd(&lds_pos[d], 1u)
-                               : static_cast<unsigned int>(offsets[m]) + atomicAdd(&cursor[m], 1u);
+    int64_t const pos    = d < in_lds ? base + static_cast<int64_t>(atomicAdd(&lds_pos[d], 1u))
+                                      : static_cast<int64_t>(offsets[m]) + static_cast<int64_t>(atomicAdd(&cursor[m], 1u));
     keys[pos] = key_of(e);
   }
 }
@@ -718,9 +722,9 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
   // long columns (512 edges or more on average): LDS-privatised histogram and scatter (hist_lds_kernel)
   bool const no_lds     = std::getenv("CUGRAPH_AMD_BUILD_NO_LDS") != nullptr;
   // (grouped: the caller says that neighbouring edges have neighbouring majors, whatever their number)
-  bool const few_majors = sizeof(OffT) == 4 && n_edges >= (int64_t{1} << 16) && (n_edges / 512 >= n_major || grouped) && !no_lds;
+  bool const few_majors = n_edges >= (int64_t{1} << 16) && (n_edges / 512 >= n_major || grouped) && !no_lds;
   // majors in descending degree order: the first kLdsMajors of them take a large share of the edges
-  bool const lds_scatter = few_majors || (sizeof(OffT) == 4 && hubs_first && n_edges >= (int64_t{1} << 16) && !no_lds);
+  bool const lds_scatter = few_majors || (hubs_first && n_edges >= (int64_t{1} << 16) && !no_lds);
   size_t const lds_bytes = static_cast<size_t>(kLdsMajors) * sizeof(unsigned int);
   int const lds_grid     = 1024;
   out.off64 = sizeof(OffT) == 8;
@@ -755,16 +759,14 @@ CompressedOut compress_impl(hipStream_t stream, int64_t n_major, int64_t n_minor
   // scatter of (major, minor[, position]) into the columns: keys of type KeyT
   auto scatter = [&](auto* keys) {
     using KeyT = std::remove_pointer_t<decltype(keys)>;
-    if constexpr (sizeof(OffT) == 4) {
-      if (lds_scatter) {
-        auto kern = scatter_lds_kernel<KeyT>;
-        CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(kLdsMajors * sizeof(unsigned int))));
-        hipLaunchKernelGGL(kern, dim3(lds_grid), dim3(1024), lds_bytes, stream, majors, minors, n_edges,
-                           out.offsets.template as<int32_t>(), counts.as<unsigned int>(), keys);
-        return;
-      }
+    if (lds_scatter && n_major > 0) {
+      auto kern = scatter_lds_kernel<OffT, KeyT>;
+      CGA_HIP(hipFuncSetAttribute(reinterpret_cast<void const*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(kLdsMajors * sizeof(unsigned int))));
+      hipLaunchKernelGGL(kern, dim3(lds_grid), dim3(1024), lds_bytes, stream, majors, minors, n_edges,
+                         out.offsets.template as<OffT>(), n_major, counts.as<unsigned int>(), keys);
+      return;
     }
     hipLaunchKernelGGL((scatter_kernel<OffT, KeyT>), dim3(grid_for(n_edges)), dim3(kThreads), 0, stream,
                        majors, minors, n_edges, out.offsets.template as<OffT>(), counts.as<unsigned int>(),
