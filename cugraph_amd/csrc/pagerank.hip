@@ -1548,6 +1548,12 @@ XsKernelChoice<ValT> xs_pick(bool weighted, int row_bits, int epl, int threads, 
                                 2 * (static_cast<int>(sizeof(double)) << RB)};
     CGA_XS2_CASE(false, 12, 8)
     CGA_XS2_CASE(false, 13, 8)
+    CGA_XS2_CASE(false, 12, 16)
+    CGA_XS2_CASE(false, 13, 16)
+    if constexpr (sizeof(ValT) == 4) {  // (fp64 weights: 12 entries a lane would spill)
+      CGA_XS2_CASE(true, 12, 12)
+      CGA_XS2_CASE(true, 13, 12)
+    }
     CGA_XS2_CASE(true, 12, 8)
     CGA_XS2_CASE(true, 13, 8)
 #undef CGA_XS2_CASE
@@ -2385,7 +2391,10 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
   int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
   if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
-  int const epl = kXsEntriesPerLane;  // (4: 1.94 ms, 16: 1.77 ms against 1.75 ms at scale 26)
+  // entries a lane keeps in flight per pass: 8 in xs_kernel (4: 1.94 ms, 16: 1.77 ms against 1.75 ms at
+  // scale 26); xs2_kernel on an unweighted graph 16 (scale 26: 1.573 ms against 1.639 with 8 and 1.583 with
+  // 12; 24 and 32 spill registers: 1.75 / 2.43; weighted graphs: 16 would spill)
+  int epl = kXsEntriesPerLane;
   // Wide workgroups (unweighted graphs): 8192-row tiles run by two 1024-thread workgroups per CU
   // instead of 16384-row tiles run by one (see xs_kernel's WPE).  CUGRAPH_AMD_XS_WIDE=0/1.
   char const* wide_env = std::getenv("CUGRAPH_AMD_XS_WIDE");
@@ -2403,6 +2412,8 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     if (row_bits > 13) row_bits = 13;
   }
   int const threads = async ? kXs2Threads : xs_threads_for(row_bits, wide);
+  if (async) epl = g.weights == nullptr ? 16 : sizeof(ValT) == 4 ? 12 : 8;
+  if (char const* epl_env = std::getenv("CUGRAPH_AMD_XS_EPL")) epl = std::atoi(epl_env);
   DevBuf flags(static_cast<size_t>(n_rows) * 4), pos(static_cast<size_t>(n_rows + 1) * 8);
   DevBuf tile_of_row(static_cast<size_t>(n_rows) * 4);
   hipLaunchKernelGGL((xs_break_flags_kernel<OffT>), dim3(grid_for(n_rows)), dim3(kThreads), 0, stream,

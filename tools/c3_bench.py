@@ -23,3 +23,7 @@ info = s.info()
 print(f"C3 scale {scale} fp64 weighted personalized: iteration {it.mean():.3f} ms, dominant kernel {km.mean():.3f} ms, "
       f"{ne / it.mean() / 1e6:.1f} GTEPS, B_iter {info['bytes_per_iteration'] / 1e9:.2f} GB -> "
       f"{info['bytes_per_iteration'] / it.mean() / 1e6:.0f} GB/s")
+import json
+print("C3JSON " + json.dumps({"scale": scale, "iteration_ms": float(it.mean()), "kernel_ms": float(km.mean()),
+                              "dominant_kernel_bytes": int(info["dominant_kernel_bytes"]),
+                              "bytes_per_iteration": int(info["bytes_per_iteration"])}))
