@@ -230,9 +230,11 @@ def extra_configs(args, handle):
                 "dtype": "f64" if weighted else "f32",
                 "ms_per_step": it, "value": ne / (it * 1e-3) / 1e9, "unit": "GTEPS",
                 "algorithmic_GBps_whole_iteration": info["bytes_per_iteration"] / (it * 1e-3) / 1e9,
-                "roofline": {"bound": "hbm", "kernel": "xs_kernel" if info["mid_degree_vertices"] else "spmv_kernel",
+                "roofline": {"bound": "hbm", "kernel": xs_name() if info["mid_degree_vertices"] else "spmv_kernel",
                              "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                             "traffic": None, "algorithmic_bytes_per_launch": info["dominant_kernel_bytes"],
+                             "traffic": pmc_traffic(scale, args.edge_factor, 1, config=name),
+                             "traffic_source": f"{PMC_FILE} (commit {pmc_file().get('commit')})",
+                             "algorithmic_bytes_per_launch": info["dominant_kernel_bytes"],
                              "kernel_ms_avg": km},
                 "graph_build": {"coo_to_csc_s": t_csc, "plan_build_s": t_plan},
             }
@@ -297,15 +299,29 @@ def main_test_double(args):
     dist.destroy_process_group()
 
 
-def pmc_traffic(scale, ef, n_gpus):
-    """HBM bytes per xs_kernel launch from the committed rocprofv3 PMC passes (profiles/), or
-    None when they do not describe this workload.  bench.py cannot run under the profiler itself."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_xs.json")
+PMC_FILE = "profiles/r3_pmc_xs.json"
+
+
+def xs_name():
+    """the XS-tile kernel the library runs: xs2_kernel (two accumulator banks, no item barriers) unless opted out"""
+    return "xs_kernel" if os.environ.get("CUGRAPH_AMD_XS_ASYNC") == "0" else "xs2_kernel"
+
+
+def pmc_file():
     try:
-        with open(path) as f:
-            d = json.load(f)
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def pmc_traffic(scale, ef, n_gpus, config=None):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/, tools/profile_r3.sh + tools/r3_pmc_fold.py), or None when they do not describe this
+    workload.  bench.py cannot run under the profiler itself; the file names the commit it was taken at."""
+    d = pmc_file()
+    if config is not None:
+        return d.get("other_configs", {}).get(config, {}).get("traffic_bytes_per_launch")
     if d.get("scale") != scale or d.get("edge_factor") != ef or n_gpus != 1:
         return None
     return d.get("traffic_bytes_per_launch")
@@ -431,14 +447,15 @@ def main():
     achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": "xs_kernel" if info["mid_degree_vertices"] and os.environ.get("CUGRAPH_AMD_XS") != "0"
+        "kernel": xs_name() if info["mid_degree_vertices"] and os.environ.get("CUGRAPH_AMD_XS") != "0"
                   else "spmv_kernel",
         "achieved": achieved,
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": pmc_traffic(scale, ef, world),
-        "traffic_source": "profiles/r2_pmc_xs.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile_r2.sh)",
+        "traffic_source": f"{PMC_FILE} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile_r3.sh; "
+                          f"taken at commit {pmc_file().get('commit')})",
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "kernel_ms_avg": kern_avg_ms,
         "iteration_ms_event_avg": float(iter_ms.mean()),

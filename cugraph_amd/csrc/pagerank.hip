@@ -64,7 +64,6 @@ constexpr int kXsMinDegree    = kLowDegreeMax + 1;
 #define CGA_XS_ALIGN 64
 #endif
 constexpr bool kXsWideDefault = false;
-constexpr int64_t kXsAsyncMinEntries = int64_t(1) << 27;  // xs2_kernel from this many XS entries on  // two 1024-thread workgroups per CU on 8192-row tiles (build_xs)
 constexpr int64_t kXsMaxDegree = 16384;  // without XS tiles: longer columns are hub work items
 
 // a packed entry is (slice-local source & (2^(32 - row_bits) - 1)) << row_bits | row in tile
@@ -2404,9 +2403,9 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // xs2_kernel (two banks of accumulators in one 1024-thread workgroup, items without barriers):
   // tiles of at most 8192 rows.  CUGRAPH_AMD_XS_ASYNC=0/1.
   char const* async_env = std::getenv("CUGRAPH_AMD_XS_ASYNC");
-  // (default: from 2^27 entries on -- scale 22: 0.125 ms with barriers against 0.128 without; scale 24:
-  // 0.403 / 0.375; scale 26: 1.668 / 1.633, profiles/r3_xs_tiles.md)
-  bool const async      = async_env ? std::atoi(async_env) != 0 : ne >= kXsAsyncMinEntries;
+  // (the default -- xs_kernel with barriers against xs2_kernel: scale 22 0.122 / 0.119 ms, scale 24
+  // 0.403 / 0.355, scale 26 1.666 / 1.571, profiles/r3_xs_diag.md)
+  bool const async      = async_env ? std::atoi(async_env) != 0 : true;
   if (async) {
     wide = false;
     if (row_bits > 13) row_bits = 13;
