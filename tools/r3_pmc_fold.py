@@ -6,20 +6,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 commit = sys.argv[1] if len(sys.argv) > 1 else subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
 
+def newest(pattern):
+    """gpurun merges a call's files into gpurun_out/ beside those of earlier calls: take the latest"""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
 def per_kernel(d, pat=r"xs2?_kernel<"):
-    f = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)
+    f = [newest(f"gpurun_out/{d}/**/*counter_collection.csv")]
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     names = set()
     for r in csv.DictReader(open(f[0])):
         if re.search(pat, r["Kernel_Name"]):
             acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-            names.add(re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cga::(anonymous namespace)::", ""))
+            names.add(re.sub(r"\(.*", "", r["Kernel_Name"].replace("void cga::(anonymous namespace)::", "")))
     out = {c: sum(v.values()) / len(v) for c, v in acc.items()}
     return out, (len(next(iter(acc.values()))) if acc else 0), sorted(names)
 
 def stats(d):
     ks = {}
-    for r in csv.DictReader(open(glob.glob(f"gpurun_out/{d}/**/*kernel_stats.csv", recursive=True)[0])):
+    for r in csv.DictReader(open(newest(f"gpurun_out/{d}/**/*kernel_stats.csv"))):
         for k in ("xs2_kernel", "xs_kernel", "spmv_kernel", "xs_finish_kernel", "finalize_kernel", "pers_fix_kernel"):
             if "::" + k + "<" in r["Name"] or "::" + k + "(" in r["Name"]:
                 ks[k] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6}
