@@ -2354,6 +2354,21 @@ int xs_row_bits_for(int64_t minor_space, int slice_shift, int max_bits = kXsRowB
   return row_bits;
 }
 
+// the two settings build_xs and xs_window_slots have to agree on (a region of the gathered vector is a
+// whole number of windows, and a window is 2^(35 - row bits) slots)
+int xs_row_bits_env(int row_bits)
+{
+  char const* rb_env = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
+  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) return std::atoi(rb_env);
+  return row_bits;
+}
+constexpr int kXs2RowBitsMax = 13;  // xs2_kernel: two banks of 8192 fp64 accumulators are the LDS it has
+bool xs_async_on()
+{
+  char const* async_env = std::getenv("CUGRAPH_AMD_XS_ASYNC");
+  return async_env ? std::atoi(async_env) != 0 : true;
+}
+
 template <typename OffT, typename ValT>
 void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
 {
@@ -2388,8 +2403,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // 0.146 / 0.129 ms, scale 24 0.503 / 0.457 / 0.438, scale 26 2.14 / 1.96 / 1.86, scale 28 (52
   // windows at 14 bits) 12.99 / 11.82 / 10.86.
   char const* rb_env  = std::getenv("CUGRAPH_AMD_XS_ROWBITS");
-  int row_bits = xs_row_bits_for(g.minor_space(), slice_shift);
-  if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) row_bits = std::atoi(rb_env);
+  int row_bits = xs_row_bits_env(xs_row_bits_for(g.minor_space(), slice_shift));
   // entries a lane keeps in flight per pass: 8 in xs_kernel (4: 1.94 ms, 16: 1.77 ms against 1.75 ms at
   // scale 26); xs2_kernel on an unweighted graph 16 (scale 26: 1.573 ms against 1.639 with 8 and 1.583 with
   // 12; 24 and 32 spill registers: 1.75 / 2.43; weighted graphs: 16 would spill)
@@ -2402,13 +2416,12 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   wide = wide && row_bits == 13;
   // xs2_kernel (two banks of accumulators in one 1024-thread workgroup, items without barriers):
   // tiles of at most 8192 rows.  CUGRAPH_AMD_XS_ASYNC=0/1.
-  char const* async_env = std::getenv("CUGRAPH_AMD_XS_ASYNC");
   // (the default -- xs_kernel with barriers against xs2_kernel: scale 22 0.122 / 0.119 ms, scale 24
   // 0.403 / 0.355, scale 26 1.666 / 1.571, profiles/r3_xs_diag.md)
-  bool const async      = async_env ? std::atoi(async_env) != 0 : true;
+  bool const async = xs_async_on();
   if (async) {
     wide = false;
-    if (row_bits > 13) row_bits = 13;
+    if (row_bits > kXs2RowBitsMax) row_bits = kXs2RowBitsMax;
   }
   int const threads = async ? kXs2Threads : xs_threads_for(row_bits, wide);
   if (async) epl = g.weights == nullptr ? 16 : sizeof(ValT) == 4 ? 12 : 8;
@@ -3529,7 +3542,9 @@ void session_iterate(Session& s, size_t n)
 int64_t xs_window_slots(int64_t num_source_slots)
 {
   if (num_source_slots <= 0) return 0;
-  return static_cast<int64_t>(kXsSlices) << (32 - xs_row_bits_for(num_source_slots, 7));
+  int row_bits = xs_row_bits_env(xs_row_bits_for(num_source_slots, 7));
+  if (xs_async_on() && row_bits > kXs2RowBitsMax) row_bits = kXs2RowBitsMax;
+  return static_cast<int64_t>(kXsSlices) << (32 - row_bits);
 }
 
 void session_iterate_phase(Session& s, int phase)
