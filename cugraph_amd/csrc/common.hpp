@@ -146,7 +146,10 @@ struct DevBuf {
 
 // rows of in-degree 1 .. kLowDegreeMax are the thread-per-row bucket of the pull SpMV (pagerank.hip)
 // and the classes the renumbering orders by their smallest source (renumber.hip)
-constexpr int kLowDegreeMax = 3;
+#ifndef CGA_LOW_DEGREE_MAX
+#define CGA_LOW_DEGREE_MAX 3  // (5: spmv 0.223 -> ?, see profiles/r3_xs_diag.md)
+#endif
+constexpr int kLowDegreeMax = CGA_LOW_DEGREE_MAX;
 
 // position of `id` in an ascending array of distinct ids, -1 if absent
 __host__ __device__ inline int64_t find_sorted(long long const* sorted, int64_t n, long long id)

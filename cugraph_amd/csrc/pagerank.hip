@@ -2583,7 +2583,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     std::sscanf(ot, "%d:%d", &only_lo, &only_hi);
     for (int t = 0; t < n_tiles; ++t) {
       int64_t const u0 = static_cast<int64_t>(t) * kXsSlices * n_win, u1 = static_cast<int64_t>(t + 1) * kXsSlices * n_win;
-      if (t < 12 || t % 50 == 0 || t == n_tiles - 1)
+      if (t < 12 || t % 50 == 0 || t == n_tiles - 1 || std::getenv("CUGRAPH_AMD_XS_TILE_LIST"))
         std::fprintf(stderr, "xs tile %d rows %d entries %lld\n", t, h_row[t + 1] - h_row[t], (long long)(h_uoff[u1] - h_uoff[u0]));
     }
   }
