@@ -147,7 +147,7 @@ struct DevBuf {
 // rows of in-degree 1 .. kLowDegreeMax are the thread-per-row bucket of the pull SpMV (pagerank.hip)
 // and the classes the renumbering orders by their smallest source (renumber.hip)
 #ifndef CGA_LOW_DEGREE_MAX
-#define CGA_LOW_DEGREE_MAX 3  // (5: spmv 0.223 -> ?, see profiles/r3_xs_diag.md)
+#define CGA_LOW_DEGREE_MAX 3  // (5 / 7 measured slower at scale 26: iteration 1.96 -> 1.98 / 2.05 ms, profiles/r3_xs_diag.md)
 #endif
 constexpr int kLowDegreeMax = CGA_LOW_DEGREE_MAX;
 
