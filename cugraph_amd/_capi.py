@@ -71,6 +71,11 @@ SIGNATURES = {
                                                 _vp, _vp, _vp, _int, _int, _int, _vpp, _vpp]),
     "cugraph_graph_free": (None, [_vp]),
     "cugraph_sg_graph_free": (None, [_vp]),
+    "cugraph_mg_graph_free": (None, [_vp]),
+    "cugraph_mg_graph_create": (_int, [_vp, ctypes.POINTER(GraphPropertiesStruct), _vp, _vp, _vp, _vp, _vp, _int,
+                                       _sz, _int, _vpp, _vpp]),
+    "cugraph_graph_create_mg": (_int, [_vp, ctypes.POINTER(GraphPropertiesStruct), _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _int, _sz, _int, _int, _int, _vpp, _vpp]),
     "cugraph_centrality_result_get_vertices": (_vp, [_vp]),
     "cugraph_centrality_result_get_values": (_vp, [_vp]),
     "cugraph_centrality_result_get_num_iterations": (_sz, [_vp]),
@@ -95,6 +100,7 @@ SIGNATURES = {
                                                                   _vpp]),
     # ---- extensions
     "cugraph_amd_create_resource_handle": (_vp, [_vp, _int, _int]),
+    "cugraph_amd_resource_handle_set_comm": (_int, [_vp, _vp, _vpp]),
     "cugraph_amd_graph_create_local": (_int, [_vp, ctypes.POINTER(GraphPropertiesStruct), _vp, _vp,
                                               _vp, _i64, _i64, _i64, _vpp, _vpp]),
     "cugraph_amd_graph_create_local_compact": (_int, [_vp, ctypes.POINTER(GraphPropertiesStruct), _vp, _vp,

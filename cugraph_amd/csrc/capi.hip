@@ -221,7 +221,7 @@ cugraph_error_code_t check_pair_types(Graph const* g, ArrayView const* v, ArrayV
                                       char const* vmsg, char const* xmsg, cugraph_error_t** error)
 {
   if (v != nullptr) {
-    if (g->vertex_type != v->type) return fail(error, CUGRAPH_INVALID_INPUT, vmsg);
+    if (mg_api_vertex_type(*g) != v->type) return fail(error, CUGRAPH_INVALID_INPUT, vmsg);
     if (x == nullptr || g->weight_type != x->type) return fail(error, CUGRAPH_INVALID_INPUT, xmsg);
   }
   return CUGRAPH_SUCCESS;
@@ -269,7 +269,8 @@ cugraph_error_code_t pagerank_entry(const cugraph_resource_handle_t* handle, cug
   a.max_iterations     = max_iterations;
   a.do_expensive_check = do_expensive_check != FALSE;
   CentralityResult* res = nullptr;
-  rc = guarded(error, [&] { res = run_pagerank(*as<Handle>(handle), *g, a); });
+  // a graph made by cugraph_mg_graph_create / cugraph_graph_create_mg: the partitioned loop (mg_capi.hip)
+  rc = guarded(error, [&] { res = g->mg ? mg_run_pagerank(*as<Handle>(handle), *g, a) : run_pagerank(*as<Handle>(handle), *g, a); });
   if (rc != CUGRAPH_SUCCESS) return rc;
   *result = reinterpret_cast<cugraph_centrality_result_t*>(res);
   // pagerank.cpp:315-318: the strict variants report non-convergence but leave *result populated
@@ -279,6 +280,16 @@ cugraph_error_code_t pagerank_entry(const cugraph_resource_handle_t* handle, cug
 }
 
 }  // namespace
+
+namespace cga {
+Graph* make_partition_graph(Handle const& h, cugraph_graph_properties_t const* props, ArrayView const& src,
+                            ArrayView const& dst, ArrayView const* weights, int64_t vertex_first,
+                            int64_t vertex_last, int64_t num_global)
+{
+  return make_graph(h, props, nullptr, &src, &dst, weights, true, false, false, false, vertex_first, vertex_last,
+                    num_global);
+}
+}  // namespace cga
 
 extern "C" {
 
@@ -610,6 +621,74 @@ cugraph_error_code_t cugraph_sg_graph_create_from_csr(
 
 void cugraph_graph_free(cugraph_graph_t* graph) { delete as<Graph>(graph); }
 void cugraph_sg_graph_free(cugraph_graph_t* graph) { cugraph_graph_free(graph); }
+void cugraph_mg_graph_free(cugraph_graph_t* graph) { cugraph_graph_free(graph); }
+
+// ------------------------------------------------------------------ multi-GPU graphs (mg_capi.hip)
+cugraph_error_code_t cugraph_amd_resource_handle_set_comm(cugraph_resource_handle_t* handle,
+                                                          const cugraph_amd_comm_t* comm, cugraph_error_t** error)
+{
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return guarded(error, [&] {
+    auto* h = as<Handle>(handle);
+    if (!comm) {
+      h->has_comm = false;
+      h->comm     = cugraph_amd_comm_t{};
+      return;
+    }
+    CGA_EXPECTS(comm->all_reduce_f64 && comm->all_gather_v && comm->all_to_all_v, CUGRAPH_INVALID_INPUT,
+                "all three collectives are required");
+    h->comm     = *comm;
+    h->has_comm = true;
+  });
+}
+
+cugraph_error_code_t cugraph_graph_create_mg(
+  cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+  cugraph_type_erased_device_array_view_t const* const* vertices,
+  cugraph_type_erased_device_array_view_t const* const* src,
+  cugraph_type_erased_device_array_view_t const* const* dst,
+  cugraph_type_erased_device_array_view_t const* const* weights,
+  cugraph_type_erased_device_array_view_t const* const* edge_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_type_ids, bool_t store_transposed,
+  size_t num_arrays, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t do_expensive_check,
+  cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  if (graph) *graph = nullptr;
+  if (error) *error = nullptr;
+  if (!handle) return fail(error, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  if (!graph) return fail(error, CUGRAPH_INVALID_INPUT, "graph pointer is NULL");
+  // graph_mg.cpp:374-380
+  if ((edge_ids == nullptr) != (edge_type_ids == nullptr))
+    return fail(error, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: either none or both of edge ids and edge types must be provided.");
+  if (edge_ids != nullptr)
+    return fail(error, CUGRAPH_NOT_IMPLEMENTED, "edge ids / edge types on a multi-GPU graph (PageRank does not read them)");
+  (void)store_transposed;     // the partition is stored by destination either way (PageRank's orientation)
+  (void)do_expensive_check;
+  return guarded(error, [&] {
+    Graph* g = mg_create_graph(*as<Handle>(handle), properties, num_arrays,
+                               reinterpret_cast<ArrayView const* const*>(vertices),
+                               reinterpret_cast<ArrayView const* const*>(src),
+                               reinterpret_cast<ArrayView const* const*>(dst),
+                               reinterpret_cast<ArrayView const* const*>(weights), drop_self_loops != FALSE,
+                               drop_multi_edges != FALSE);
+    *graph = reinterpret_cast<cugraph_graph_t*>(g);
+  });
+}
+
+cugraph_error_code_t cugraph_mg_graph_create(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src, const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed, size_t num_edges,
+  bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  (void)num_edges;  // unused in the reference too (graph_mg.cpp, mg_test_utils.cpp:202)
+  return cugraph_graph_create_mg(handle, properties, nullptr, &src, &dst, weights ? &weights : nullptr,
+                                 edge_ids ? &edge_ids : nullptr, edge_type_ids ? &edge_type_ids : nullptr,
+                                 store_transposed, 1, FALSE, FALSE, do_expensive_check, graph, error);
+}
 
 cugraph_error_code_t cugraph_amd_graph_create_local(
   const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,

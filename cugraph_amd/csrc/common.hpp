@@ -56,6 +56,10 @@ struct Handle {
   int device{0};
   int comm_size{1};
   int rank{0};
+  // the caller's collectives (cugraph_amd_resource_handle_set_comm): what the C-level multi-GPU path
+  // (mg_capi.hip) exchanges through; unset on a single-GPU handle
+  cugraph_amd_comm_t comm{};
+  bool has_comm{false};
 };
 
 inline size_t dtype_size(cugraph_data_type_id_t t)
@@ -182,6 +186,9 @@ struct ExtLookup {
 // num_edges < 2^31, else int64 -- the same switch as cpp/src/c_api/graph_sg.cpp:568-572.
 struct PullPlan;  // pagerank.hip
 
+struct MgInfo;
+void destroy_mg_info(MgInfo* m);
+
 struct Graph {
   cugraph_data_type_id_t vertex_type{INT32};  // type of the ids the caller handed over / gets back
   cugraph_data_type_id_t edge_type{INT32};
@@ -219,6 +226,7 @@ struct Graph {
   long long* ext_sorted{nullptr};
 
   PullPlan* plan{nullptr};  // cached by the first PageRank call on this graph
+  MgInfo* mg{nullptr};      // graphs made by cugraph_mg_graph_create / cugraph_graph_create_mg (mg_capi.hip)
   Graph* reversed{nullptr};  // the other orientation without weights, cached by the first HITS call
 
   int64_t minor_space() const { return num_source_slots > 0 ? num_source_slots : num_global_vertices; }
@@ -347,6 +355,12 @@ struct PagerankArgs {
 };
 
 CentralityResult* run_pagerank(Handle const& h, Graph& g, PagerankArgs const& a);
+// ---------------------------------------------------------------- mg_capi.hip
+Graph* mg_create_graph(Handle const& h, cugraph_graph_properties_t const* props, size_t n,
+                       ArrayView const* const* vertices, ArrayView const* const* src, ArrayView const* const* dst,
+                       ArrayView const* const* weights, bool drop_self_loops, bool drop_multi_edges);
+CentralityResult* mg_run_pagerank(Handle const& h, Graph& g, PagerankArgs const& a);
+cugraph_data_type_id_t mg_api_vertex_type(Graph const& g);
 void destroy_plan(PullPlan* p);
 
 // ---------------------------------------------------------------- centrality.hip

@@ -919,6 +919,7 @@ Graph::~Graph()
   if (ext_sorted) (void)hipFree(ext_sorted);
   if (x_pos) (void)hipFree(x_pos);
   if (plan) destroy_plan(plan);
+  if (mg) destroy_mg_info(mg);
   delete reversed;
 }
 

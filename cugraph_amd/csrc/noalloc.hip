@@ -68,6 +68,17 @@ __global__ __launch_bounds__(kThreads) void sums_from_staged_kernel(int32_t cons
   }
 }
 
+// header and sums to zero.  A kernel, not hipMemsetAsync: memset nodes of a captured HIP graph were seen
+// to write stale argument bytes (the address of a later kernel's argument) into the header from the second
+// replay on (ROCm 7.0 runtime, tests/test_zz_no_alloc.py: the capture test), kernel nodes replay exactly.
+__global__ __launch_bounds__(kThreads) void clear_kernel(unsigned long long* __restrict__ header,
+                                                         double* __restrict__ sums, int64_t n)
+{
+  if (blockIdx.x == 0 && threadIdx.x < kHeaderBytes / sizeof(unsigned long long)) header[threadIdx.x] = 0ull;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    sums[i] = 0.0;
+}
+
 __global__ void publish_skipped_kernel(unsigned long long const* __restrict__ skipped, long long* __restrict__ out)
 {
   out[0] = static_cast<long long>(skipped[0]);
@@ -108,8 +119,8 @@ void edgelist_source_sums_noalloc(Handle const& h, ArrayView const& src, ArrayVi
   hipStream_t st = h.stream;
   // the array keeps the last call's contents: the counter must start at zero (the staged ids are
   // all rewritten before they are read)
-  CGA_HIP(hipMemsetAsync(skipped, 0, kHeaderBytes, st));
-  if (num_vertices > 0) CGA_HIP(hipMemsetAsync(sums, 0, static_cast<size_t>(num_vertices) * sizeof(double), st));
+  hipLaunchKernelGGL(clear_kernel, dim3(grid_for(num_vertices)), dim3(kThreads), 0, st, skipped, sums,
+                     num_vertices > 0 ? num_vertices : int64_t{0});
   if (ne > 0) {
     int const grid = grid_for(static_cast<int64_t>(ne));
     if (src.type == INT32)

@@ -284,6 +284,58 @@ cugraph_error_code_t cugraph_hits(
 cugraph_resource_handle_t* cugraph_amd_create_resource_handle(void* hip_stream, int rank,
                                                               int comm_size);
 
+
+/* ---- multi-GPU graphs under the reference's names ----
+ * cugraph_mg_graph_create (cpp/include/cugraph_c/graph.h:242, deprecated there but what
+ * cpp/tests/c_api/mg_test_utils.cpp:194 calls) and cugraph_graph_create_mg (graph.h:299): every rank (one
+ * process per GPU, handle made by cugraph_amd_create_resource_handle(stream, rank, size)) passes ANY share of
+ * the edge list -- an empty one is fine -- and the graph that comes back holds the edges whose DESTINATION the
+ * rank owns (1D partition, equal vertex ranges).  cugraph_pagerank*, cugraph_personalized_pagerank* on such a
+ * graph run the partitioned power iteration and return the (vertex, rank) pairs of the vertices this rank owns,
+ * as cpp/src/c_api/pagerank.cpp does with an MG handle (initial guess and personalization: any share of the
+ * list per rank, shuffled to the owners below this boundary, pagerank.cpp:140-144; every rank must make the
+ * call).  Differences from the reference, all checked and reported: vertex ids must be 0 .. V-1 (V = largest
+ * id + 1 over all ranks; the reference renumbers arbitrary ids), no edge ids / types, no drop_* flags, no
+ * precomputed out-weight sums (the graph keeps its own), vertices[] only extends the id range.
+ *
+ * The library has no communication dependency of its own: the collectives come from the caller, once per
+ * handle.  All pointers are DEVICE pointers; a callback must order itself after the work already enqueued on
+ * `hip_stream` and leave its result visible to work enqueued on `hip_stream` after it returns (e.g. call RCCL
+ * on that stream); it returns 0 on success.  `send` of all_gather_v may be this rank's own place inside
+ * `recv`.  op: 0 = sum, 1 = max.  No counterpart in the reference (raft::comms plays this role there). */
+typedef struct {
+  void* context;
+  int (*all_reduce_f64)(void* context, double* buffer, size_t count, int op, void* hip_stream);
+  int (*all_gather_v)(void* context, const void* send, void* recv, const size_t* bytes_per_rank, void* hip_stream);
+  int (*all_to_all_v)(void* context, const void* send, const size_t* send_bytes_per_rank, void* recv,
+                      const size_t* recv_bytes_per_rank, void* hip_stream);
+} cugraph_amd_comm_t;
+
+cugraph_error_code_t cugraph_amd_resource_handle_set_comm(cugraph_resource_handle_t* handle,
+                                                          const cugraph_amd_comm_t* comm, cugraph_error_t** error);
+
+cugraph_error_code_t cugraph_mg_graph_create(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* src, const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed, size_t num_edges,
+  bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+
+cugraph_error_code_t cugraph_graph_create_mg(
+  cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+  cugraph_type_erased_device_array_view_t const* const* vertices,
+  cugraph_type_erased_device_array_view_t const* const* src,
+  cugraph_type_erased_device_array_view_t const* const* dst,
+  cugraph_type_erased_device_array_view_t const* const* weights,
+  cugraph_type_erased_device_array_view_t const* const* edge_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_type_ids, bool_t store_transposed,
+  size_t num_arrays, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t do_expensive_check,
+  cugraph_graph_t** graph, cugraph_error_t** error);
+
+/* graph.h:337 (deprecated twin of cugraph_graph_free) */
+void cugraph_mg_graph_free(cugraph_graph_t* graph);
+
 /* Local part of a 1D destination-partitioned graph: this rank owns destinations
  * [vertex_first, vertex_last) of num_global_vertices and must be given exactly the edges whose
  * dst lies in that range (any src).  Always stored transposed (CSC, global source ids). */

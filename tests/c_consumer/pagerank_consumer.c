@@ -12,6 +12,7 @@
  * lines "vertex value".  Output: one line "vertex value" per vertex, then "converged <0|1>".
  * Exit status 0 when every call succeeded. */
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "cugraph_amd_c.h"
@@ -41,10 +42,13 @@ static int to_device(const cugraph_resource_handle_t* handle, const void* host, 
 
 int main(int argc, char** argv)
 {
-  if (argc != 2) {
-    fprintf(stderr, "usage: %s <case file>\n", argv[0]);
+  if (argc != 2 && !(argc == 3 && strcmp(argv[2], "mg") == 0)) {
+    fprintf(stderr, "usage: %s <case file> [mg]\n", argv[0]);
     return 2;
   }
+  /* "mg": the same case through the multi-GPU entry points at world size 1, as
+   * cpp/tests/c_api/mg_pagerank_test.c:67-94 runs it (create_mg_test_graph -> cugraph_mg_graph_create) */
+  int const mg = argc == 3;
   FILE* f = fopen(argv[1], "r");
   if (!f) {
     perror(argv[1]);
@@ -69,7 +73,8 @@ int main(int argc, char** argv)
 
   cugraph_error_t* err = NULL;
   cugraph_error_code_t code;
-  cugraph_resource_handle_t* handle = cugraph_create_resource_handle(NULL);
+  cugraph_resource_handle_t* handle =
+    mg ? cugraph_amd_create_resource_handle(NULL, 0, 1) : cugraph_create_resource_handle(NULL);
   if (!handle) {
     fprintf(stderr, "cugraph_create_resource_handle failed\n");
     return 1;
@@ -89,9 +94,13 @@ int main(int argc, char** argv)
   props.is_multigraph = FALSE;
   cugraph_graph_t* graph = NULL;
   /* as create_test_graph of the reference's tests: no vertex list, no renumbering */
-  code = cugraph_graph_create_sg(handle, &props, NULL, v_src, v_dst, v_wgt, NULL, NULL,
-                                 transposed ? TRUE : FALSE, FALSE, FALSE, FALSE, FALSE, &graph, &err);
-  CHECK(code, err, "cugraph_graph_create_sg");
+  if (mg)
+    code = cugraph_mg_graph_create(handle, &props, v_src, v_dst, v_wgt, NULL, NULL, transposed ? TRUE : FALSE, ne,
+                                   FALSE, &graph, &err);
+  else
+    code = cugraph_graph_create_sg(handle, &props, NULL, v_src, v_dst, v_wgt, NULL, NULL,
+                                   transposed ? TRUE : FALSE, FALSE, FALSE, FALSE, FALSE, &graph, &err);
+  CHECK(code, err, mg ? "cugraph_mg_graph_create" : "cugraph_graph_create_sg");
 
   cugraph_centrality_result_t* result = NULL;
   if (n_pers && allow)
@@ -127,7 +136,10 @@ int main(int argc, char** argv)
   cugraph_type_erased_device_array_view_free(vertices);
   cugraph_type_erased_device_array_view_free(values);
   cugraph_centrality_result_free(result);
-  cugraph_sg_graph_free(graph);
+  if (mg)
+    cugraph_mg_graph_free(graph);
+  else
+    cugraph_sg_graph_free(graph);
   cugraph_type_erased_device_array_view_free(v_src);
   cugraph_type_erased_device_array_view_free(v_dst);
   cugraph_type_erased_device_array_view_free(v_wgt);

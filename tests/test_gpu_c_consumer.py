@@ -18,8 +18,11 @@ with open(os.path.join(HERE, "golden", "reference_vectors.json")) as _f:
     CASES = json.load(_f)["c_api"]["cases"]
 
 
+@pytest.mark.parametrize("entry", ["sg", "mg"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_c_program_reproduces_the_reference_goldens(name, tmp_path):
+def test_c_program_reproduces_the_reference_goldens(name, entry, tmp_path):
+    """entry "mg": the same cases through cugraph_mg_graph_create and an MG handle of one rank, the way
+    cpp/tests/c_api/mg_pagerank_test.c runs the same graphs (its goldens are pagerank_test.c's)."""
     assert os.path.exists(BINARY), "tests/c_consumer/pagerank_consumer is built by __graft_entry__.build()"
     c = CASES[name]
     src, dst, wgt = case_arrays(c)
@@ -30,7 +33,8 @@ def test_c_program_reproduces_the_reference_goldens(name, tmp_path):
     lines += [f"{v} {x!r}" for v, x in pers]
     case_file = tmp_path / "case.txt"
     case_file.write_text("\n".join(lines) + "\n")
-    r = subprocess.run([BINARY, str(case_file)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([BINARY, str(case_file)] + (["mg"] if entry == "mg" else []), capture_output=True, text=True,
+                       timeout=120)
     assert r.returncode == 0, r.stderr
     out = r.stdout.split("\n")
     got = {}

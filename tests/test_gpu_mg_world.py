@@ -63,6 +63,33 @@ def test_driver_with_ranks_sharing_one_gpu_over_gloo(mode, layout, world):
     assert r.stdout.count("iterations, max-abs") == world
 
 
+@pytest.mark.parametrize("world,mode,share,what", [
+    (2, "unweighted", "round-robin", "plain"),
+    (2, "weighted", "rank0", "personalized"),
+    (3, "unweighted", "rank0", "personalized"),
+    (3, "weighted", "round-robin", "plain"),
+    (1, "unweighted", "round-robin", "personalized"),
+])
+def test_multi_gpu_graph_and_pagerank_through_the_c_names(world, mode, share, what):
+    """cugraph_mg_graph_create + cugraph_[personalized_]pagerank on an MG handle (cugraph_amd/csrc/mg_capi.hip),
+    the way cpp/tests/c_api/mg_pagerank_test.c:67-94 drives the reference: ranks sharing GPU 0, the library's
+    three collectives supplied as ctypes callbacks over gloo (tests/mg_capi_worker.py), every rank's pairs and
+    the iteration count against the CPU oracle.  share "rank0": rank 0 passes every edge and the others none,
+    as create_mg_test_graph does (mg_test_utils.cpp:157-163)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CUGRAPH_AMD_XS_MIN_EDGES="65536", CUGRAPH_AMD_TEST_DUMP_AFTER="100")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(HERE, "mg_capi_worker.py"), "16", mode, share, what],
+                       capture_output=True, text=True, timeout=170, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.stdout.count("iterations, max-abs") == world
+
+
 @pytest.mark.parametrize("id_dtype", [torch.int32, torch.int64])
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("world", [1, 3, 8])
