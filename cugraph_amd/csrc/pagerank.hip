@@ -3048,6 +3048,10 @@ int session_geometry(Session& s, PullPlan& plan)
     bk.block_begin = begin;
     begin += bk.n_blocks;
   }
+  // the slot-numbered indices of a plan with XS tiles are cut down to the rows below the tiles
+  // (PullPlan::compact_tail): no bucket that reads the rows above them may run on it
+  CGA_EXPECTS(!plan.compact_tail.p || (s.buckets[0].count == 0 && s.buckets[1].count == 0 && s.buckets[2].count == 0),
+              CUGRAPH_UNKNOWN_ERROR, "internal: a degree bucket of XS rows on a plan whose slot copy is trimmed");
   // XS tiles run in their own launch (xs_kernel): 4096 threads per CU whatever the workgroup size
   s.xs_block_begin = 0;
   s.n_xs_blocks    = 0;
