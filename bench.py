@@ -493,8 +493,9 @@ def main():
         conv = {"iterations": it, "converged": bool(stopped), "seconds": dt,
                 "seconds_including_build": t_csc + t_plan + dt,
                 "l1_delta": delta, "epsilon": eps,
-                "note": "NetworkX's stop rule, sum|dx| < N*tol: at N = 2^26 the threshold is 0.67, so the "
-                        "first iteration already meets it (networkx.pagerank stops there too)"}
+                "note": f"NetworkX's stop rule, sum|dx| < N*tol with tol 1e-8: at N = 2^{args.scale} the threshold is "
+                        f"{eps:.3g}" + (", so the first iteration already meets it (networkx.pagerank stops there too)"
+                                        if it <= 1 else "")}
         del s2
         # the same run to an ABSOLUTE L1 threshold (cugraph's own epsilon semantics, pagerank_impl.cuh:328-335)
         eps_abs = 1e-6

@@ -107,7 +107,9 @@ def main():
     scale = int(sys.argv[1])
     weighted = sys.argv[2] == "weighted"
     share = sys.argv[3]  # "round-robin": every rank a share; "rank0": rank 0 everything (mg_test_utils.cpp:163)
-    personalized = len(sys.argv) > 4 and sys.argv[4] == "personalized"
+    what = sys.argv[4] if len(sys.argv) > 4 else "plain"
+    personalized = what == "personalized"
+    guess = what == "guess"  # + the graph through cugraph_graph_create_mg with its share in two arrays
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if os.environ.get("CUGRAPH_AMD_TEST_DUMP_AFTER"):
         import faulthandler
@@ -131,11 +133,22 @@ def main():
         _capi.check(lib.cugraph_amd_resource_handle_set_comm(h.c_resource_handle_ptr, ctypes.byref(comm),
                                                              ctypes.byref(err)), err, "set_comm")
         props = GraphPropertiesStruct(False, True)
-        views = [create_view_from_py_obj(t) for t in (t_src, t_dst, t_wgt)]
         graph = ctypes.c_void_p()
-        code = lib.cugraph_mg_graph_create(h.c_resource_handle_ptr, ctypes.byref(props), views[0], views[1], views[2],
-                                           None, None, 1, ne, 0, ctypes.byref(graph), ctypes.byref(err))
-        _capi.check(code, err, "cugraph_mg_graph_create")
+        if guess:
+            cut = t_src.numel() // 3
+            parts = [(t_src[:cut].contiguous(), t_dst[:cut].contiguous(), None if t_wgt is None else t_wgt[:cut].contiguous()),
+                     (t_src[cut:].contiguous(), t_dst[cut:].contiguous(), None if t_wgt is None else t_wgt[cut:].contiguous())]
+            views = [create_view_from_py_obj(t) for part in parts for t in part]
+            arr = lambda k: (ctypes.c_void_p * 2)(views[k], views[3 + k])  # noqa: E731
+            lists = [arr(0), arr(1), arr(2) if t_wgt is not None else None]
+            code = lib.cugraph_graph_create_mg(h.c_resource_handle_ptr, ctypes.byref(props), None, lists[0], lists[1],
+                                               lists[2], None, None, 1, 2, 0, 0, 0, ctypes.byref(graph), ctypes.byref(err))
+            _capi.check(code, err, "cugraph_graph_create_mg")
+        else:
+            views = [create_view_from_py_obj(t) for t in (t_src, t_dst, t_wgt)]
+            code = lib.cugraph_mg_graph_create(h.c_resource_handle_ptr, ctypes.byref(props), views[0], views[1], views[2],
+                                               None, None, 1, ne, 0, ctypes.byref(graph), ctypes.byref(err))
+            _capi.check(code, err, "cugraph_mg_graph_create")
         eps = 1e-7
         result = ctypes.c_void_p()
         pers = None
@@ -152,6 +165,20 @@ def main():
             code = lib.cugraph_personalized_pagerank(h.c_resource_handle_ptr, graph, None, None, None, None, pviews[0],
                                                      pviews[1], 0.85, eps, 200, 0, ctypes.byref(result), ctypes.byref(err))
             pers = (pv, px / px.sum())
+        elif guess:  # an initial guess for every vertex, all of it handed in by the LAST rank
+            rng = np.random.default_rng(4)
+            g0 = rng.random(nv) + 0.5
+            g0 /= g0.sum()
+            vdt = torch.float64 if weighted else torch.float32
+            if rank == world - 1:
+                t_gv = torch.arange(nv).to(id_dtype).cuda()
+                t_gx = torch.from_numpy(g0).to(vdt).cuda()
+                gviews = [create_view_from_py_obj(t_gv), create_view_from_py_obj(t_gx)]
+            else:
+                gviews = [None, None]
+            code = lib.cugraph_pagerank(h.c_resource_handle_ptr, graph, None, None, gviews[0], gviews[1], 0.85, eps, 200, 0,
+                                        ctypes.byref(result), ctypes.byref(err))
+            nstart = torch.from_numpy(g0).to(vdt).numpy().astype(np.float64)  # as the library saw it
         else:
             fn = lib.cugraph_pagerank_allow_nonconvergence if os.environ.get("MG_CAPI_DEBUG") else lib.cugraph_pagerank
             code = fn(h.c_resource_handle_ptr, graph, None, None, None, None, 0.85, eps, 200, 0,
@@ -170,6 +197,8 @@ def main():
         conv = lib.cugraph_centrality_result_converged(result)
         off, idx, perm = oracle.compress(nv, dst, src)
         kw = {}
+        if guess:
+            kw = dict(nstart=nstart)
         if pers is not None:
             kw = dict(pers_vertices=pers[0], pers_values=pers[1])
         o_pr, o_it, o_conv = oracle.pagerank(nv, off, idx, None if wgt is None else wgt[perm], dtype=np.float64,

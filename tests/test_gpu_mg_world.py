@@ -69,6 +69,8 @@ def test_driver_with_ranks_sharing_one_gpu_over_gloo(mode, layout, world):
     (3, "unweighted", "rank0", "personalized"),
     (3, "weighted", "round-robin", "plain"),
     (1, "unweighted", "round-robin", "personalized"),
+    (2, "unweighted", "round-robin", "guess"),
+    (3, "weighted", "round-robin", "guess"),
 ])
 def test_multi_gpu_graph_and_pagerank_through_the_c_names(world, mode, share, what):
     """cugraph_mg_graph_create + cugraph_[personalized_]pagerank on an MG handle (cugraph_amd/csrc/mg_capi.hip),
