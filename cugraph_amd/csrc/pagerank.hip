@@ -28,6 +28,8 @@
 // thread-per-row and isolated buckets.  The path is a sparse HBM-bound contraction: no MFMA.
 #include "common.hpp"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -2375,6 +2377,16 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   int64_t row_first = plan.firsts[0];
   int64_t n_rows    = plan.counts[0] + plan.counts[1] + plan.counts[2];
   if (n_rows == 0) return;
+  // CUGRAPH_AMD_PLAN_PROFILE=1: seconds between the marks of this function, on stderr (synchronises at each)
+  bool const prof = std::getenv("CUGRAPH_AMD_PLAN_PROFILE") != nullptr;
+  auto t_last     = std::chrono::steady_clock::now();
+  auto mark       = [&](char const* what) {
+    if (!prof) return;
+    (void)hipStreamSynchronize(stream);
+    auto const now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "xs plan: %-28s %.4f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   OffT const* offsets = static_cast<OffT const*>(g.offsets);
   OffT h_off[2];
   CGA_HIP(hipMemcpyAsync(&h_off[0], offsets + row_first, sizeof(OffT), hipMemcpyDeviceToHost, stream));
@@ -2436,6 +2448,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipMemcpyAsync(&n_tiles64, pos.as<int64_t>() + n_rows, 8, hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
   int n_tiles     = static_cast<int>(n_tiles64);
+  mark("tile cuts");
   // windows of 2^(32 - row_bits) slice-local source positions: a packed entry carries only those bits
   uint32_t max_local = xs_slice_local(static_cast<uint32_t>(g.minor_space() - 1), slice_shift) |
                        ((1u << slice_shift) - 1u);
@@ -2469,6 +2482,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
                      n_win, row_bits, unit.as<int32_t>(), row_of_edge.as<int32_t>(),
                      plan.xs_tile_row.as<int32_t>(), packed_keys ? row_of_edge.as<uint32_t>() : nullptr, sub_bits);
   CGA_HIP(hipGetLastError());
+  mark("labels");
   plan.xs_unit_off.alloc(static_cast<size_t>(n_units + 1) * sizeof(int64_t));
   if (packed_keys) {
     CompressedOut c = compress_coo_keys(stream, n_units << sub_bits, ne, unit.as<int32_t>(),
@@ -2511,6 +2525,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     CGA_HIP(hipGetLastError());
     CGA_HIP(hipStreamSynchronize(stream));
   }
+  mark("group + sort");
   if (std::getenv("CUGRAPH_AMD_XS_VERIFY")) {
     DevBuf out(24);
     CGA_HIP(hipMemsetAsync(out.p, 0, 24, stream));
@@ -2549,6 +2564,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   CGA_HIP(hipMemcpyAsync(h_row.data(), plan.xs_tile_row.p, static_cast<size_t>(n_tiles + 1) * 4,
                          hipMemcpyDeviceToHost, stream));
   CGA_HIP(hipStreamSynchronize(stream));
+  mark("unit offsets to host");
   // Source PARTS (single GPU; big and medium tiles): a unit is cut at window boundaries into
   // parts of part_windows windows -- about 3 MiB of the gathered vector per XCD slice, what an
   // XCD's L2 holds beside the streams -- and the queue is ordered part-major: first every such
@@ -2649,6 +2665,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
     }
   }
   h_pbase[n_tiles] = plen;
+  mark("work items (host)");
   if (n_tiles >= (1 << 24) || h_items[0].size() + h_items[1].size() >= 0x7fffffffu / kXsSlices) return;
   plan.xs_pbase.alloc(static_cast<size_t>(n_tiles + 1) * 8);
   CGA_HIP(hipMemcpyAsync(plan.xs_pbase.p, h_pbase.data(), plan.xs_pbase.bytes, hipMemcpyHostToDevice, stream));
@@ -2669,6 +2686,7 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   plan.xs_fin_items.alloc(h_fin.size() * 8);
   CGA_HIP(hipMemcpy(plan.xs_fin_items.p, h_fin.data(), h_fin.size() * 8, hipMemcpyHostToDevice));
   plan.xs_n_fin_items = static_cast<int>(h_fin.size() / 4);
+  mark("records");
   plan.xs_regions     = w0 > 0 ? 2 : 1;
   plan.xs_partial_len = plen;
   plan.xs_on        = true;
