@@ -2402,6 +2402,15 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // fill the chip.  Small scales are flat in both knobs (scale 22: 0.235 ms from 1 M to 4 M).
   int64_t tile_edges = kXsTileEdges;
   while (tile_edges > (int64_t(1) << 16) && tile_edges * 32 > ne) tile_edges >>= 1;
+  // From 120 M entries on there are enough work items either way, and tiles of 16 M entries gather from
+  // fewer distinct lines than tiles of ne / 32 -- what a rank of a partitioned graph needs most, whose few
+  // rows face the whole source space (round 3, same box: one rank of 8 / of 4 at scale 26 0.351 -> 0.315 /
+  // 0.573 -> 0.539 ms per iteration; single GPU scale 24 0.352 -> 0.347 ms; below that the smaller tiles
+  // win: scale 22 0.119 against 0.136 ms with 4 M, one rank of 8 at scale 24 0.135 / 0.151).  (ne / 32
+  // stays where it is the larger: 64 M from scale 28 on.)  Beyond 16 M the iteration still gains (-2.5 % at
+  // scale 26 with 128 M, -7 % for one rank of 8 at scale 28 with 64 M) but the plan build -- one workgroup
+  // sorts each hot column of a tile -- pays more than a run of a few hundred iterations gets back.
+  if (ne >= 120000000LL) tile_edges = std::max(tile_edges, int64_t(1) << 24);
   if (te_env) tile_edges = std::atoll(te_env);
   char const* sh_env  = std::getenv("CUGRAPH_AMD_XS_SLICE_SHIFT");
   int slice_shift     = sh_env ? std::atoi(sh_env) : 7;
