@@ -230,7 +230,7 @@ def extra_configs(args, handle):
                 "dtype": "f64" if weighted else "f32",
                 "ms_per_step": it, "value": ne / (it * 1e-3) / 1e9, "unit": "GTEPS",
                 "algorithmic_GBps_whole_iteration": info["bytes_per_iteration"] / (it * 1e-3) / 1e9,
-                "roofline": {"bound": "hbm", "kernel": xs_name() if info["mid_degree_vertices"] else "spmv_kernel",
+                "roofline": {"bound": "hbm", "kernel": xs_name(info) if info["mid_degree_vertices"] else "spmv_kernel",
                              "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                              "traffic": pmc_traffic(scale, args.edge_factor, 1, config=name),
                              "traffic_source": f"{PMC_FILE} (commit {pmc_file().get('commit')})",
@@ -302,9 +302,15 @@ def main_test_double(args):
 PMC_FILE = "profiles/r3_pmc_xs.json"
 
 
-def xs_name():
-    """the XS-tile kernel the library runs: xs2_kernel (two accumulator banks, no item barriers) unless opted out"""
-    return "xs_kernel" if os.environ.get("CUGRAPH_AMD_XS_ASYNC") == "0" else "xs2_kernel"
+def xs_name(info):
+    """the XS-tile kernel the library runs: xs2_kernel (two accumulator banks, no item barriers) for plans from
+    40 M entries on (build_xs, kXs2MinEntries), the barrier kernel xs_kernel below that or under
+    CUGRAPH_AMD_XS_ASYNC=0.  (The entry count is estimated from the kernel's algorithmic bytes: 4 per entry plus
+    the vectors; the two only disagree within a few per cent of the threshold.)"""
+    env = os.environ.get("CUGRAPH_AMD_XS_ASYNC")
+    if env is not None:
+        return "xs_kernel" if env == "0" else "xs2_kernel"
+    return "xs2_kernel" if info["dominant_kernel_bytes"] / 4.2 >= 40e6 else "xs_kernel"
 
 
 def pmc_file():
@@ -447,7 +453,7 @@ def main():
     achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": xs_name() if info["mid_degree_vertices"] and os.environ.get("CUGRAPH_AMD_XS") != "0"
+        "kernel": xs_name(info) if info["mid_degree_vertices"] and os.environ.get("CUGRAPH_AMD_XS") != "0"
                   else "spmv_kernel",
         "achieved": achieved,
         "peak": HBM_PEAK_GBPS,

@@ -2364,6 +2364,7 @@ int xs_row_bits_env(int row_bits)
   if (rb_env && std::atoi(rb_env) >= kXsRowBits && std::atoi(rb_env) <= kXsRowBitsMax) return std::atoi(rb_env);
   return row_bits;
 }
+constexpr int64_t kXs2MinEntries = 40000000;  // XS entries from which xs2_kernel is the default
 constexpr int kXs2RowBitsMax = 13;  // xs2_kernel: two banks of 8192 fp64 accumulators are the LDS it has
 bool xs_async_on()
 {
@@ -2439,7 +2440,12 @@ void build_xs(hipStream_t stream, Graph const& g, PullPlan& plan)
   // tiles of at most 8192 rows.  CUGRAPH_AMD_XS_ASYNC=0/1.
   // (the default -- xs_kernel with barriers against xs2_kernel: scale 22 0.122 / 0.119 ms, scale 24
   // 0.403 / 0.355, scale 26 1.666 / 1.571, profiles/r3_xs_diag.md)
-  bool const async = xs_async_on();
+  // (small plans keep the barrier kernel: their items are too few for two banks to pay -- scale 19 / 20 / 21:
+  // 0.044 / 0.051 / 0.074 ms against 0.073 / 0.065 / 0.077 with xs2_kernel; scale 22, 62 M entries: 0.122 / 0.119.
+  // A graph with two regions follows the setting alone, so that the window size cugraph_amd_xs_window_slots
+  // announced is the one its tiles get.)
+  char const* async_env = std::getenv("CUGRAPH_AMD_XS_ASYNC");
+  bool const async      = xs_async_on() && (async_env != nullptr || ne >= kXs2MinEntries || g.hot_slots > 0);
   if (async) {
     wide = false;
     if (row_bits > kXs2RowBitsMax) row_bits = kXs2RowBitsMax;

@@ -27,7 +27,7 @@ def _random_graph(rng, kind):
     return nv, src.astype(np.int64), dst.astype(np.int64)
 
 
-@pytest.mark.parametrize("engine", ["buckets", "xs", "xs_forced_layouts"])
+@pytest.mark.parametrize("engine", ["buckets", "xs", "xs_forced_layouts", "xs2", "xs2_forced_layouts"])
 @pytest.mark.parametrize("seed", range(12))
 def test_random_graphs_and_options(seed, engine, monkeypatch):
     import oracle
@@ -37,7 +37,9 @@ def test_random_graphs_and_options(seed, engine, monkeypatch):
         monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", str(1 << 40))
     else:
         monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0")
-    if engine == "xs_forced_layouts":
+    if engine.startswith("xs2"):  # xs2_kernel instead of the barrier kernel small plans get by default
+        monkeypatch.setenv("CUGRAPH_AMD_XS_ASYNC", "1")
+    if engine.endswith("forced_layouts"):
         monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1")
         monkeypatch.setenv("CUGRAPH_AMD_RENUMBER_LOCALITY", "1")
         monkeypatch.setenv("CUGRAPH_AMD_XS_TILE_EDGES", "64")
@@ -90,7 +92,7 @@ def test_random_graphs_and_options(seed, engine, monkeypatch):
             assert bool(out[2]) == o_conv, what
 
 
-@pytest.mark.parametrize("engine", ["buckets", "xs_forced_layouts"])
+@pytest.mark.parametrize("engine", ["buckets", "xs_forced_layouts", "xs2_forced_layouts"])
 @pytest.mark.parametrize("seed", range(6))
 def test_random_graphs_katz_and_hits(seed, engine, monkeypatch):
     """The sibling power iterations on the same random graphs: Katz (always convergent for alpha
@@ -100,6 +102,8 @@ def test_random_graphs_katz_and_hits(seed, engine, monkeypatch):
     from cugraph_amd import pylibcugraph as plc
 
     monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", str(1 << 40) if engine == "buckets" else "0")
+    if engine.startswith("xs2"):
+        monkeypatch.setenv("CUGRAPH_AMD_XS_ASYNC", "1")
     if engine != "buckets":
         monkeypatch.setenv("CUGRAPH_AMD_COMPACT", "1")
         monkeypatch.setenv("CUGRAPH_AMD_RENUMBER_LOCALITY", "1")

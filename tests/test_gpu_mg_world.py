@@ -53,6 +53,8 @@ def test_driver_with_ranks_sharing_one_gpu_over_gloo(mode, layout, world):
     env.pop("CUGRAPH_AMD_MG_EXCHANGE", None)
     if layout == "personal":
         env["CUGRAPH_AMD_MG_EXCHANGE"] = "personal"
+    if layout != "one-region":  # xs2_kernel, the kernel of full-size plans (small plans default to the barrier kernel)
+        env["CUGRAPH_AMD_XS_ASYNC"] = "1"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",

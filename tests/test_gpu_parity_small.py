@@ -139,7 +139,7 @@ def test_rmat_generator_matches_oracle(scale, ef, scramble):
 @pytest.mark.parametrize("scale", [10, 14, 17])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("weighted", [False, True])
-@pytest.mark.parametrize("xs_tiles", [False, True])
+@pytest.mark.parametrize("xs_tiles", [False, True, "xs2"])
 def test_rmat_pagerank_vs_oracle(scale, dtype, weighted, xs_tiles, monkeypatch):
     """R-MAT (hubs, multi-edges, self-loops, dangling and isolated vertices): CSC bit-exact, ranks
     within 1e-6 (fp32) / 1e-10 (fp64) max-abs of the C oracle, same iteration count."""
@@ -148,6 +148,8 @@ def test_rmat_pagerank_vs_oracle(scale, dtype, weighted, xs_tiles, monkeypatch):
 
     # the XS tile path (mid-degree rows) is only chosen for big graphs unless forced
     monkeypatch.setenv("CUGRAPH_AMD_XS_MIN_EDGES", "0" if xs_tiles else str(1 << 40))
+    if xs_tiles == "xs2":  # xs2_kernel (two accumulator banks) is the default only from 40 M entries on
+        monkeypatch.setenv("CUGRAPH_AMD_XS_ASYNC", "1")
     nv, ne = 1 << scale, 16 << scale
     src, dst = oracle.rmat_edges(scale, ne, seed=42)
     wgt = oracle.rmat_weights(ne, seed=43).astype(dtype) if weighted else None
