@@ -507,7 +507,8 @@ class MGPagerank:
             slot = slot_of_vertex[src]
             return x_pos, slot, n_own, uniq
 
-        personal = world > 1 and exchange_mode(world) == "personal"
+        # (with one rank only when asked for by name: a test of the path itself, its foreign block is empty)
+        personal = exchange_mode(world) == "personal" and (world > 1 or os.environ.get("CUGRAPH_AMD_MG_EXCHANGE") == "personal")
         if personal:
             x_pos, src_slot, n_own, uniq = assign_private_slots()
         else:

@@ -519,3 +519,44 @@ def test_phase_0_reads_only_the_hot_region():
                        capture_output=True, text=True, timeout=400, env=env, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "region check: 0 gathers beyond region 0" in r.stdout
+
+
+def test_personalised_exchange_over_rccl_with_one_rank(monkeypatch):
+    """The default exchange from 2 ranks on (private slots + one all_to_all_single into library-owned memory
+    behind the own sources) forced onto the driver with ONE rank over RCCL, collectives on: the foreign
+    block is empty, so the all-to-all moves nothing -- what this covers is what one GPU can cover of that
+    path with the real backend (the tensors that alias the session's vector, split lists, stream order);
+    results against the single-GPU run.  Scale 22: XS tiles, xs2_kernel."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from cugraph_amd import mg, pylibcugraph as plc
+
+    monkeypatch.setenv("CUGRAPH_AMD_MG_EXCHANGE", "personal")
+    scale = 22
+    nv = 1 << scale
+    eps = 1e-6
+    h0, g0, src, dst, _ = _rmat_graph(scale)
+    v, r, conv = plc.pagerank(h0, g0, None, None, None, None, 0.85, eps, 100, False, fail_on_nonconvergence=False)
+    want = r.cpu().numpy().astype(np.float64)
+    assert conv
+    del g0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29521")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        h = plc.ResourceHandle(rank=0, comm_size=1)
+        drv = mg.MGPagerank.from_edges(mg.HipEngine(h, plc.GraphProperties(is_multigraph=True)), src.clone(),
+                                       dst.clone(), None, nv, rank=0, world=1)
+        assert drv.idx_give is not None and drv.n_foreign == 0 and drv.n_own > 0
+        drv.always_exchange = True
+        sess = drv.session(alpha=0.85, epsilon=eps)
+        iters, stopped, _ = drv.run_to_convergence(sess, 100, check_every=3)
+        full, it2, conv2 = drv.gathered_result(sess, 100)
+        assert stopped and conv2
+        assert np.max(np.abs(full.cpu().numpy().astype(np.float64) - want)) <= 1e-7
+    finally:
+        if own:
+            dist.destroy_process_group()
