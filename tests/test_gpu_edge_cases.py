@@ -253,3 +253,72 @@ def test_do_expensive_check_of_the_pagerank_call():
     with pytest.raises(RuntimeError, match="peresonalization values should be non-negative"):
         plc.personalized_pagerank(h, g, None, None, None, None, to_dev(np.array([0, 1], np.int32)),
                                   to_dev(np.array([1.0, -0.25], np.float32)), 0.85, 1e-6, 100, True)
+
+
+def test_multi_gpu_c_entry_points_reject_what_they_do_not_do():
+    """cugraph_mg_graph_create / cugraph_graph_create_mg (cugraph_amd/csrc/mg_capi.hip): the documented
+    differences from the reference are errors, not silent behaviour."""
+    import ctypes
+
+    import torch
+
+    from cugraph_amd import _capi, pylibcugraph as plc
+    from cugraph_amd._capi import GraphPropertiesStruct
+    from cugraph_amd.pylibcugraph.utils import create_view_from_py_obj, free_view
+
+    lib = _capi.load()
+    props = GraphPropertiesStruct(False, True)
+    src = torch.tensor([0, 1, 2, 2], dtype=torch.int32, device="cuda")
+    dst = torch.tensor([1, 2, 0, 1], dtype=torch.int32, device="cuda")
+    v_src, v_dst = create_view_from_py_obj(src), create_view_from_py_obj(dst)
+
+    def create(handle, s=v_src, d=v_dst, drop=0):
+        graph, err = ctypes.c_void_p(), ctypes.c_void_p()
+        arr = lambda v: (ctypes.c_void_p * 1)(v)  # noqa: E731
+        code = lib.cugraph_graph_create_mg(handle.c_resource_handle_ptr, ctypes.byref(props), None, arr(s), arr(d), None,
+                                           None, None, 1, 1, drop, 0, 0, ctypes.byref(graph), ctypes.byref(err))
+        _capi.check(code, err, "cugraph_graph_create_mg")
+        return graph
+
+    # more than one rank needs the collectives of the handle
+    with pytest.raises(Exception, match="cugraph_amd_resource_handle_set_comm"):
+        create(plc.ResourceHandle(rank=0, comm_size=2))
+    h = plc.ResourceHandle(rank=0, comm_size=1)
+    with pytest.raises(Exception, match="drop_self_loops / drop_multi_edges"):
+        create(h, drop=1)
+    neg = torch.tensor([0, -1, 2, 2], dtype=torch.int32, device="cuda")
+    v_neg = create_view_from_py_obj(neg)
+    with pytest.raises(Exception, match="non-negative"):
+        create(h, s=v_neg)
+    # a good graph, then: precomputed sums are not taken, a vertex outside the graph is refused
+    graph = create(h)
+    ids = torch.arange(3, dtype=torch.int32, device="cuda")
+    ones = torch.ones(3, dtype=torch.float32, device="cuda")
+    v_ids, v_ones = create_view_from_py_obj(ids), create_view_from_py_obj(ones)
+    result, err = ctypes.c_void_p(), ctypes.c_void_p()
+    code = lib.cugraph_pagerank(h.c_resource_handle_ptr, graph, v_ids, v_ones, None, None, 0.85, 1e-6, 20, 0,
+                                ctypes.byref(result), ctypes.byref(err))
+    with pytest.raises(Exception, match="precomputed out-weight sums on a multi-GPU graph"):
+        _capi.check(code, err, "cugraph_pagerank")
+    far = torch.tensor([7], dtype=torch.int32, device="cuda")
+    one = torch.ones(1, dtype=torch.float32, device="cuda")
+    v_far, v_one = create_view_from_py_obj(far), create_view_from_py_obj(one)
+    code = lib.cugraph_personalized_pagerank(h.c_resource_handle_ptr, graph, None, None, None, None, v_far, v_one, 0.85,
+                                             1e-6, 20, 0, ctypes.byref(result), ctypes.byref(err))
+    with pytest.raises(Exception, match="not in the graph"):
+        _capi.check(code, err, "cugraph_personalized_pagerank")
+    # and the plain call works: 3-cycle with a chord, ranks sum to one
+    code = lib.cugraph_pagerank(h.c_resource_handle_ptr, graph, None, None, None, None, 0.85, 1e-9, 200, 0,
+                                ctypes.byref(result), ctypes.byref(err))
+    _capi.check(code, err, "cugraph_pagerank")
+    x_view = lib.cugraph_centrality_result_get_values(result)
+    vals = np.empty(3, dtype=np.float32)
+    code = lib.cugraph_type_erased_device_array_view_copy_to_host(h.c_resource_handle_ptr, vals.ctypes.data, x_view,
+                                                                  ctypes.byref(err))
+    _capi.check(code, err, "copy_to_host")
+    assert abs(float(vals.sum()) - 1.0) < 1e-5
+    lib.cugraph_type_erased_device_array_view_free(x_view)
+    lib.cugraph_centrality_result_free(result)
+    lib.cugraph_mg_graph_free(graph)
+    for v in (v_src, v_dst, v_neg, v_ids, v_ones, v_far, v_one):
+        free_view(v)
