@@ -207,14 +207,16 @@ Graph* mg_create_graph(Handle const& h, cugraph_graph_properties_t const* props,
     CGA_EXPECTS(!have_type || src[i]->type == vtype, CUGRAPH_INVALID_INPUT, "Invalid input arguments: all arrays of a list must have one type.");
     vtype     = src[i]->type;
     have_type = true;
-    if (have_w) {
-      CGA_EXPECTS(weights[i] && weights[i]->size == src[i]->size, CUGRAPH_INVALID_INPUT,
+    if (have_w && weights[i]) {
+      CGA_EXPECTS(weights[i]->size == src[i]->size, CUGRAPH_INVALID_INPUT,
                   "Invalid input arguments: src size != weights size.");
       CGA_EXPECTS(weights[i]->type == FLOAT32 || weights[i]->type == FLOAT64, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
                   "edge weights must be FLOAT32 or FLOAT64");
       CGA_EXPECTS(ws.empty() || weights[i]->type == wtype, CUGRAPH_INVALID_INPUT, "Invalid input arguments: all arrays of a list must have one type.");
       wtype = weights[i]->type;
       ws.push_back(weights[i]);
+    } else if (have_w) {  // graph.h:221-228: a rank without edges may pass a NULL weights pointer
+      CGA_EXPECTS(src[i]->size == 0, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src size != weights size.");
     }
     ss.push_back(src[i]);
     ds.push_back(dst[i]);
@@ -226,6 +228,18 @@ Graph* mg_create_graph(Handle const& h, cugraph_graph_properties_t const* props,
     }
   }
   CGA_EXPECTS(ne < 0x7fffffffLL * 2, CUGRAPH_INVALID_INPUT, "too many edges in one rank's share");
+  // Whether the graph is weighted, and in which type, is a property of all ranks together: a rank without
+  // edges may have passed no weights at all.  Agreed here, so that every rank makes the same collectives (and
+  // a disagreement fails on every rank instead of leaving the others inside one).
+  {
+    double const mine   = ws.empty() ? 0.0 : wtype == FLOAT64 ? 2.0 : 1.0;
+    double const agreed = comm.reduce_scalar(mine, 1);
+    double const bad    = comm.reduce_scalar((mine != 0.0 && mine != agreed) || (mine == 0.0 && agreed != 0.0 && ne > 0) ? 1.0 : 0.0, 1);
+    CGA_EXPECTS(bad == 0.0, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: the ranks disagree on the edge weights (present on some, or of two types).");
+    have_w = agreed != 0.0;
+    wtype  = agreed == 2.0 ? FLOAT64 : FLOAT32;
+  }
   size_t const wsz = have_w ? dtype_size(wtype) : 0;
 
   // ---- this rank's share as int32 ids (+ weights), end to end; the id range over all ranks

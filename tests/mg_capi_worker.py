@@ -127,6 +127,8 @@ def main():
         t_src = torch.from_numpy(np.ascontiguousarray(src[sel])).to(id_dtype).cuda()
         t_dst = torch.from_numpy(np.ascontiguousarray(dst[sel])).to(id_dtype).cuda()
         t_wgt = None if wgt is None else torch.from_numpy(np.ascontiguousarray(wgt[sel])).cuda()
+        if share == "rank0" and rank != 0:
+            t_wgt = None  # (graph.h:221-228: a rank without edges may pass a NULL weights pointer)
         h = plc.ResourceHandle(rank=rank, comm_size=world)
         comm, keep = make_comm(rank, world)
         err = ctypes.c_void_p()
